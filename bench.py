@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the point-to-plane ICP hot path on MI355X.
+
+A step is one registration of a synthetic 1024^2-point pair with analytic
+normals, 30 iterations, clouds resident in HBM (BASELINE.json configs[1]).
+With N > 1 ranks every rank registers its own independent pair (batch mode,
+no data-path collective) and `value` is the aggregate iterations/s; the same
+run also times the sharded mode (one 4096^2-point pair split over the ranks,
+one 32-double all-reduce per iteration) and reports it under "sharded".
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+      --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--side", type=int, default=1024, help="points per cloud = side^2")
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--sharded-side", type=int, default=4096,
+                    help="side of the pair of the sharded leg; 0 disables the leg")
+    ap.add_argument("--cpu-iters", type=int, default=8,
+                    help="iterations of the CPU baseline sample; 0 disables it")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+    from stereovision_amd.sharded import HipShardEngine, run_sharded, shard_bounds
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n = args.side * args.side
+    tgt, nrm, src, pose = synth.make_pair(args.side, pair=rank)
+    ctx = sv.Context(local)
+    t0 = time.perf_counter()
+    ctx.set_target(tgt, nrm)
+    grid_build_s = time.perf_counter() - t0
+    ctx.set_source(src)
+
+    # ---- primary: K registrations of `iters` iterations each -------------
+    for _ in range(args.warmup):
+        T, info = ctx.run(args.iters)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        T, info = ctx.run(args.iters)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * args.steps * args.iters / elapsed
+
+    # ---- per-kernel durations: the same steps, eager, HIP events on the
+    # library's stream around every launch -------------------------------
+    ctx.set_options(time_kernels=1)
+    fused, solve = [], []
+    for _ in range(max(2, min(args.steps, 5))):
+        ctx.run(args.iters)
+        f, s, _ = ctx.kernel_times()
+        fused.append(f)
+        solve.append(s)
+    ctx.set_options(time_kernels=0)
+    fused_ms, solve_ms = float(np.mean(fused)), float(np.mean(solve))
+    # algorithmic bytes of one launch of the fused kernel: source read + write
+    # (24 B/pt), target xyz + normal + index (28 B/pt), each touched once
+    bytes_fused = 24.0 * n + 28.0 * len(tgt)
+    achieved = bytes_fused / (fused_ms * 1e-3) / 1e9
+    nn_capped_ms = ctx.time_nn(exact=False, reps=20)
+    nn_exact_ms = ctx.time_nn(exact=True, reps=20)
+    bytes_nn = 20.0 * n + 16.0 * len(tgt)
+
+    # ---- sharded leg ----------------------------------------------------
+    sharded = None
+    if args.sharded_side > 0:
+        st, sn, ss, _ = synth.make_pair(args.sharded_side, pair=0)
+        b, e = shard_bounds(len(ss), world, rank)
+        sctx = sv.Context(local)
+        sctx.set_target(st, sn)
+        sctx.set_source(np.ascontiguousarray(ss[b:e]))
+        del ss
+        if distributed:
+            eng = HipShardEngine(sctx, f"cuda:{local}")
+            run_sharded(eng, args.iters)
+            barrier()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                Ts, _ = run_sharded(eng, args.iters)
+            barrier()
+            dt = time.perf_counter() - t0
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        else:
+            sctx.run(args.iters)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                Ts, _ = sctx.run(args.iters)
+            dt = time.perf_counter() - t0
+        sharded = {
+            "workload": f"one {args.sharded_side}^2-point pair, source split over {world} rank(s), "
+                        "target replicated, 32-double all-reduce per iteration",
+            "iters_per_s": reps * args.iters / dt,
+            "scaling": "strong",
+        }
+        sctx.close()
+
+    # ---- CPU baseline: the oracle on the same pair, one thread ------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_iters > 0:
+        from oracle import pyoracle as po
+        tree = po.KDTree(tgt)                       # index build excluded, as test.cpp:20-21
+        t0 = time.perf_counter()
+        r = po.icp_point2plane(tree, nrm, src, args.cpu_iters, faithful=True, threads=1,
+                               history=False)
+        dt = time.perf_counter() - t0
+        Xg, _ = ctx.history()
+        cpu = {
+            "value": args.cpu_iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": f"first {args.cpu_iters} of {args.iters} iterations of the same "
+                      f"{n}-point pair, kd-tree build excluded, restated reference "
+                      "(oracle/icp_oracle.c; the reference needs FLANN+Eigen and cannot be built)",
+            "host_cpus": os.cpu_count(),
+            "max_abs_X_diff_vs_gpu": float(np.abs(Xg[: args.cpu_iters] - r["X"]).max()),
+        }
+
+    if rank == 0:
+        out = {
+            "metric": "point-to-plane ICP iters/s at 1M pts",
+            "value": value,
+            "unit": "iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 points and rows, f64 accumulate and solve",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[1]: synthetic {args.side}^2-point source/target pair with "
+                            f"normals, point-to-plane ICP, {args.iters} iters per step, "
+                            "one independent pair per GPU",
+                "points": n, "iters_per_step": args.iters,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "icp_accumulate_kernel",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": bytes_fused, "launch_ms": fused_ms,
+            },
+            "cpu_baseline": cpu,
+            "kernels_ms": {"icp_accumulate": fused_ms, "reduce_solve": solve_ms,
+                           "nn1_capped": nn_capped_ms, "nn1_exact": nn_exact_ms},
+            "nn_queries_per_s": {"capped": n / (nn_capped_ms * 1e-3),
+                                 "exact": n / (nn_exact_ms * 1e-3),
+                                 "capped_GBs": bytes_nn / (nn_capped_ms * 1e-3) / 1e9},
+            "grid_build_ms": grid_build_s * 1e3,
+            "final_step_norm": info.step_norm,
+            "sharded": sharded,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

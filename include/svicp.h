@@ -1,0 +1,186 @@
+/*
+ * svicp.h - C ABI of libsvicp.so: point-to-plane ICP registration and exact
+ * k-nearest-neighbour search on one AMD MI355X (gfx950) per context.
+ *
+ * Every entry point returns an int status (SVICP_OK == 0).  No exception, C++
+ * type or framework type crosses this boundary: plain pointers and sizes only.
+ * Unless a parameter says "device", pointers are host pointers owned by the
+ * caller; the library copies what it needs during the call.
+ *
+ * One context is used by one host thread at a time.  Contexts are independent.
+ *
+ * The entry points replace the public surface of the reference's registration
+ * classes (paths relative to the reference repository):
+ *   PointCloud/Registration/CPoint2PlaneICP.h:11-17
+ *   PointCloud/Registration/CKNNSearch.h:12-17
+ * Each declaration cites the member it stands in for.
+ */
+#ifndef SVICP_H
+#define SVICP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svicp_ctx svicp_ctx;
+
+enum {
+    SVICP_OK = 0,
+    SVICP_ERR_ARG = 1,       /* null pointer, negative size, wrong call order      */
+    SVICP_ERR_HIP = 2,       /* a HIP runtime call failed (see svicp_last_error)   */
+    SVICP_ERR_GRID = 3,      /* target extent / cell edge too large for the grid   */
+    SVICP_ERR_SINGULAR = 4,  /* the 6x6 normal matrix was not positive definite    */
+    SVICP_ERR_NO_DEVICE = 5  /* no gfx950 device / library built without a device  */
+};
+
+/* Tunables.  Defaults are the reference's hard-coded constants. */
+typedef struct svicp_options {
+    float dist_threshold;  /* squared-distance cut-off of the weight function, 5.0
+                              (CPoint2PlaneICP.cpp:68)                                */
+    int normals_k;         /* neighbours per normal estimate, 20 (CPoint2PlaneICP.cpp:125) */
+    int use_graph;         /* 1: svicp_run replays a captured HIP graph of the whole
+                              iteration loop; 0: eager launches                       */
+    int time_kernels;      /* 1: eager launches bracketed by HIP events so that
+                              svicp_kernel_times reports per-kernel durations         */
+    int sort_source;       /* 1: keep the source in Morton order on the device (the
+                              caller-visible order is unchanged)                      */
+    int blocks_per_cu;     /* launch width of the per-iteration kernel, default 4     */
+} svicp_options;
+
+/* Per-run summary.  Arrays hold the LAST iteration's figures. */
+typedef struct svicp_info {
+    int iterations;        /* solves performed (== the requested count)              */
+    int status;            /* SVICP_OK or SVICP_ERR_SINGULAR                          */
+    double inliers;        /* correspondences with non-zero weight                    */
+    double weighted_sq_residual; /* sum w * b^2 over correspondences                  */
+    double step_norm;      /* |X| of the last 6-vector                                */
+    double weight_sum;     /* sum w                                                   */
+} svicp_info;
+
+/* ---- lifetime ------------------------------------------------------- */
+
+/* CPoint2PlaneICP::CPoint2PlaneICP() / CKNNSearch::CKNNSearch()
+ * (CPoint2PlaneICP.cpp:3-6, CKNNSearch.cpp:3-8).  device_id is the HIP device
+ * ordinal the context lives on. */
+int svicp_create(int device_id, svicp_ctx **out);
+
+/* ~CPoint2PlaneICP / ~CKNNSearch (CPoint2PlaneICP.cpp:7-10, CKNNSearch.cpp:10-25). */
+int svicp_destroy(svicp_ctx *ctx);
+
+/* Text of the last failure on this context (or of the last failed
+ * svicp_create when ctx is NULL).  Never NULL. */
+const char *svicp_last_error(const svicp_ctx *ctx);
+
+int svicp_default_options(svicp_options *opt);
+int svicp_set_options(svicp_ctx *ctx, const svicp_options *opt);
+int svicp_get_options(const svicp_ctx *ctx, svicp_options *opt);
+
+/* ---- target ("reference data") -------------------------------------- */
+
+/* CPoint2PlaneICP::setReferenceData (CPoint2PlaneICP.cpp:11-18) and
+ * CKNNSearch::setTreeData (CKNNSearch.cpp:27-35).
+ * xyz_aos: m x 3 fp32 row-major (the flann::Matrix<float> layout).
+ * normals_aos: m x 3 fp32 unit normals, or NULL to estimate them the way
+ * CPoint2PlaneICP::calcNormals does (CPoint2PlaneICP.cpp:122-154).
+ * Builds the search grid on the device. */
+int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const float *normals_aos);
+
+/* The normals in use (m x 3 fp32, caller order): the ones passed in, or the
+ * estimated ones (m_pNormals, CPoint2PlaneICP.h:26). */
+int svicp_get_normals(svicp_ctx *ctx, float *normals_aos_out);
+
+/* ---- source ("move data") ------------------------------------------- */
+
+/* CPoint2PlaneICP::setMoveData (CPoint2PlaneICP.cpp:19-22) and
+ * CKNNSearch::setQueryData (CKNNSearch.cpp:37-54).  n x 3 fp32 row-major.
+ * The library keeps its own device copy; the caller's buffer is not retained. */
+int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n);
+
+/* The source cloud as the last svicp_run left it: transformed iterations-1
+ * times, the state the reference leaves in the caller's buffer
+ * (CPoint2PlaneICP.cpp:42-50).  n x 3 fp32, caller order. */
+int svicp_get_source(svicp_ctx *ctx, float *xyz_aos_out);
+
+/* ---- registration ---------------------------------------------------- */
+
+/* CPoint2PlaneICP::setMaxIterateCount + run (CPoint2PlaneICP.cpp:27-62).
+ * Always runs exactly `iterations` solves from the source as svicp_set_source
+ * gave it (the reference has no convergence test: m_eps is never read).
+ * T_out: accumulated 4x4 rigid transform, row-major fp64 (the matrix the
+ * reference prints at CPoint2PlaneICP.cpp:58).  info may be NULL.
+ * All iterations run on the device without a host round trip. */
+int svicp_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info);
+
+/* Per-iteration record of the last svicp_run: X_out iterations x 6 (the
+ * solution vector X of CPoint2PlaneICP.cpp:109), info_out iterations x 4
+ * {inliers, sum w b^2, |X|, sum w}.  Either may be NULL. */
+int svicp_get_history(svicp_ctx *ctx, double *X_out, double *info_out);
+
+/* 1-NN correspondences of the current source against the target, as used by
+ * the last solve (CPoint2PlaneICP.cpp:65-67).  idx_out, d2_out: n entries,
+ * caller order.  Only neighbours within dist_threshold matter to the solve;
+ * a point with none closer gets idx -1 and d2 +inf. */
+int svicp_correspondences(svicp_ctx *ctx, int32_t *idx_out, float *d2_out);
+
+/* ---- exact k-NN ------------------------------------------------------ */
+
+/* CKNNSearch::setQueryData + setKCount + getKNeighbour (CKNNSearch.cpp:37-71).
+ * Exact k nearest target points of each query, k clamped to 128 as
+ * setKCount does (CKNNSearch.cpp:60-65).  idx_out: n x k int32 row-major,
+ * d2_out: n x k SQUARED distances fp32, ascending; equal distances are ordered
+ * by ascending index.  Missing neighbours (k > m): idx -1, d2 +inf. */
+int svicp_knn(svicp_ctx *ctx, const float *query_aos, int64_t n, int k,
+              int32_t *idx_out, float *d2_out);
+
+/* ---- sharded registration (one context per GPU) ---------------------- */
+/* A large registration shards the source over ranks; every rank holds the
+ * whole target.  Per iteration each rank calls svicp_shard_accumulate, the
+ * caller sums the 32-double blocks of all ranks (RCCL all-reduce), and each
+ * rank calls svicp_shard_update with the sum.  The reference has no multi-
+ * device path; these split CPoint2PlaneICP::singleRun (CPoint2PlaneICP.cpp:63-120)
+ * at the one point where ranks exchange data. */
+
+/* Launches on `hip_stream` (a hipStream_t, e.g. the caller framework's
+ * current stream) from now on.  NULL is the device's default stream, not
+ * "no change"; svicp_use_own_stream goes back to the context's private
+ * non-blocking stream (the initial state). */
+int svicp_set_stream(svicp_ctx *ctx, void *hip_stream);
+int svicp_use_own_stream(svicp_ctx *ctx);
+
+/* Resets the accumulated transform and the iteration counter. */
+int svicp_shard_begin(svicp_ctx *ctx);
+
+/* Transforms this rank's source shard by the previous update, finds
+ * correspondences and writes this rank's partial sums: 21 upper-triangle
+ * JtJ entries, 6 Jtr entries, {inliers, sum w b^2, sum w}, padding to 32
+ * doubles, to device memory `dev_partial32`. */
+int svicp_shard_accumulate(svicp_ctx *ctx, double *dev_partial32);
+
+/* Solves from the globally summed block (device memory) and updates the
+ * rank's copy of R, T and the accumulated transform. */
+int svicp_shard_update(svicp_ctx *ctx, const double *dev_sum32);
+
+/* Copies out the accumulated transform after the last svicp_shard_update. */
+int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info);
+
+/* ---- measurement ----------------------------------------------------- */
+
+/* Average duration in milliseconds, over the last svicp_run made with
+ * options.time_kernels = 1, of the per-iteration correspondence+accumulate
+ * kernel and of the solve kernel, and the number of launches averaged. */
+int svicp_kernel_times(svicp_ctx *ctx, double *fused_ms, double *solve_ms, int *launches);
+
+/* Runs the standalone 1-NN kernel `reps` times over the resident source and
+ * reports its average duration.  exact = 0: radius-capped search as the ICP
+ * loop uses it; exact = 1: unbounded exact search. */
+int svicp_time_nn(svicp_ctx *ctx, int exact, int reps, double *avg_ms);
+
+/* Sizes of the resident clouds. */
+int svicp_sizes(const svicp_ctx *ctx, int64_t *m, int64_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVICP_H */

@@ -1,0 +1,151 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The shipped package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "icp_oracle.c")
+    if force or not os.path.exists(so) or (
+        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        fp = C.POINTER(C.c_float)
+        ip = C.POINTER(C.c_int32)
+        dp = C.POINTER(C.c_double)
+        L.orc_kdtree_build.restype = C.c_void_p
+        L.orc_kdtree_build.argtypes = [fp, C.c_int64]
+        L.orc_kdtree_free.argtypes = [C.c_void_p]
+        L.orc_kdtree_knn.argtypes = [C.c_void_p, fp, C.c_int64, C.c_int, ip, fp, C.c_int]
+        L.orc_knn_brute.argtypes = [fp, C.c_int64, fp, C.c_int64, C.c_int, ip, fp]
+        L.orc_eig3_smallest.argtypes = [dp, dp, dp]
+        L.orc_calc_normals.argtypes = [C.c_void_p, fp, C.c_int64, fp, ip, C.c_int]
+        L.orc_icp_point2plane.restype = C.c_int
+        L.orc_icp_point2plane.argtypes = [
+            C.c_void_p, fp, fp, fp, C.c_int64, C.c_int, dp, dp, ip, fp, dp, C.c_int, C.c_int,
+        ]
+        L.orc_parse_txt.restype = C.c_int64
+        L.orc_parse_txt.argtypes = [C.c_char_p, C.c_int64, fp, C.c_int64]
+        L.orc_max_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _cloud(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] == 3
+    return a
+
+
+class KDTree:
+    """Exact kd-tree over an (M, 3) fp32 cloud; stands in for flann KDTREE_SINGLE."""
+
+    def __init__(self, ref):
+        self.ref = _cloud(ref)
+        self._h = lib().orc_kdtree_build(_f(self.ref), self.ref.shape[0])
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_kdtree_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def knn(self, q, k=1, threads=1):
+        q = _cloud(q)
+        n = q.shape[0]
+        idx = np.empty((n, k), np.int32)
+        d2 = np.empty((n, k), np.float32)
+        lib().orc_kdtree_knn(self._h, _f(q), n, k, _i(idx), _f(d2), threads)
+        return idx, d2
+
+
+def knn_brute(ref, q, k=1):
+    ref = _cloud(ref)
+    q = _cloud(q)
+    n = q.shape[0]
+    idx = np.empty((n, k), np.int32)
+    d2 = np.empty((n, k), np.float32)
+    lib().orc_knn_brute(_f(ref), ref.shape[0], _f(q), n, k, _i(idx), _f(d2))
+    return idx, d2
+
+
+def eig3_smallest(W):
+    W = np.ascontiguousarray(W, dtype=np.float64).reshape(9)
+    v = np.empty(3, np.float64)
+    ev = C.c_double(0)
+    lib().orc_eig3_smallest(_d(W), _d(v), C.byref(ev))
+    return v, ev.value
+
+
+def calc_normals(tree, threads=1, want_knn=False):
+    m = tree.ref.shape[0]
+    normals = np.empty((m, 3), np.float32)
+    knn = np.empty((m, 20), np.int32) if want_knn else None
+    lib().orc_calc_normals(
+        tree._h, _f(tree.ref), m, _f(normals), _i(knn) if want_knn else None, threads
+    )
+    return (normals, knn) if want_knn else normals
+
+
+def icp_point2plane(tree, normals, src, iters, faithful=True, threads=1, history=True):
+    """Runs the restated CPoint2PlaneICP::run.  Returns a dict; src is copied, the
+    updated copy is returned as 'src' (the reference updates the caller's buffer)."""
+    src = _cloud(src).copy()
+    normals = _cloud(normals)
+    n = src.shape[0]
+    trans = np.empty(16, np.float64)
+    X = np.empty((iters, 6), np.float64)
+    info = np.empty((iters, 4), np.float64)
+    idx = np.empty((iters, n), np.int32) if history else None
+    d2 = np.empty((iters, n), np.float32) if history else None
+    rc = lib().orc_icp_point2plane(
+        tree._h, _f(tree.ref), _f(normals), _f(src), n, iters, _d(trans), _d(X),
+        _i(idx) if history else None, _f(d2) if history else None, _d(info),
+        1 if faithful else 0, threads,
+    )
+    return dict(rc=rc, trans=trans.reshape(4, 4), X=X, info=info, idx=idx, d2=d2, src=src)
+
+
+def parse_txt(text: bytes):
+    n = lib().orc_parse_txt(text, len(text), None, 0)
+    out = np.empty(n, np.float32)
+    lib().orc_parse_txt(text, len(text), _f(out), n)
+    return out[: (n // 3) * 3].reshape(-1, 3)
+
+
+def max_threads():
+    return lib().orc_max_threads()

@@ -1,0 +1,12 @@
+"""MI355X-native point-to-plane ICP registration (gfx950 HIP kernels behind a C ABI).
+
+Python mirror of the reference's registration classes:
+CPoint2PlaneICP, CKNNSearch, CTxtReader (PointCloud/Registration/*.h).
+"""
+from ._lib import Info, Options, SvicpError, load  # noqa: F401
+from .icp import CKNNSearch, CPoint2PlaneICP, CTxtReader, Context  # noqa: F401
+
+__all__ = [
+    "CKNNSearch", "CPoint2PlaneICP", "CTxtReader", "Context", "Info", "Options",
+    "SvicpError", "load",
+]

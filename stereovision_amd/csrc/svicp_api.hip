@@ -1,0 +1,876 @@
+// Host side of libsvicp.so: the C ABI declared in include/svicp.h.
+// Owns device memory, builds the search grid, launches the kernels of
+// svicp_device.hpp and replays the iteration loop as one HIP graph.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "svicp.h"
+#include "svicp_device.hpp"
+
+using namespace svicp;
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = std::max<size_t>(bytes, 256);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace
+
+struct svicp_ctx {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    svicp_options opt{};
+    std::string err;
+
+    // target
+    int64_t m = 0;
+    bool have_target = false;
+    GridDesc g{};
+    int nranked = 0;
+    DevBuf tgt_aos, nrm_aos, pts, nrm, dir, run2, end1;
+
+    // source
+    int64_t n = 0;
+    bool have_source = false, sorted = false;
+    int cur = 0;   // 0: the pristine copy is current, 1: the work copy
+    DevBuf sx0, sy0, sz0, wx, wy, wz, perm;
+
+    // scratch shared by the set-up steps
+    DevBuf tmp_aos, keys_a, keys_b, vals_a, vals_b, marks, ranks, block_of_rank, sort_tmp, bbox6;
+    DevBuf knn_idx, knn_d2, unresolved, n_unres;
+
+    // iteration loop
+    DevBuf partials, state, xhist, ihist;
+    IcpState *h_state = nullptr;   // pinned
+    int hist_cap = 0, last_iters = 0;
+    int nb = 0, chunk = 0;
+    hipGraphExec_t gexec = nullptr;
+    int g_iters = -1;
+
+    // timing
+    std::vector<hipEvent_t> events;
+    double fused_ms = 0, solve_ms = 0;
+    int timed_launches = 0;
+
+    int shard_iter = 0;
+};
+
+namespace {
+
+int fail(svicp_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) return fail(ctx, SVICP_ERR_HIP, #call, e_);         \
+    } while (0)
+
+#define LAUNCHCHK(what)                                                           \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) return fail(ctx, SVICP_ERR_HIP, what, e_);          \
+    } while (0)
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+void drop_graph(svicp_ctx *ctx)
+{
+    if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
+    ctx->g_iters = -1;
+}
+
+// bounding box of an n x 3 device array; returns through mn/mx
+int device_bbox(svicp_ctx *ctx, const float *aos, int64_t n, float mn[3], float mx[3])
+{
+    const int nblk = 256;
+    HIPCHK(ctx->bbox6.reserve(sizeof(float) * 6 * nblk));
+    hipLaunchKernelGGL(bbox_kernel, dim3(nblk), dim3(kBlockThreads), 0, ctx->stream, aos,
+                       (long long)n, ctx->bbox6.as<float>());
+    LAUNCHCHK("bbox_kernel");
+    std::vector<float> h(6 * nblk);
+    HIPCHK(hipMemcpyAsync(h.data(), ctx->bbox6.p, sizeof(float) * 6 * nblk, hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int a = 0; a < 3; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
+    for (int b = 0; b < nblk; ++b)
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(mn[a], h[6 * b + a]);
+            mx[a] = std::max(mx[a], h[6 * b + 3 + a]);
+        }
+    return SVICP_OK;
+}
+
+int sort_pairs(svicp_ctx *ctx, int64_t count, int bits)
+{
+    HIPCHK(ctx->keys_b.reserve(sizeof(unsigned long long) * count));
+    HIPCHK(ctx->vals_b.reserve(sizeof(int) * count));
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, ctx->keys_a.as<unsigned long long>(),
+                                     ctx->keys_b.as<unsigned long long>(), ctx->vals_a.as<int>(),
+                                     ctx->vals_b.as<int>(), (size_t)count, 0u, (unsigned)bits,
+                                     ctx->stream));
+    HIPCHK(ctx->sort_tmp.reserve(bytes));
+    HIPCHK(rocprim::radix_sort_pairs(ctx->sort_tmp.p, bytes, ctx->keys_a.as<unsigned long long>(),
+                                     ctx->keys_b.as<unsigned long long>(), ctx->vals_a.as<int>(),
+                                     ctx->vals_b.as<int>(), (size_t)count, 0u, (unsigned)bits,
+                                     ctx->stream));
+    return SVICP_OK;
+}
+
+// exact k-NN of n device-resident AoS queries; results to device idx/d2 (n x k)
+int run_knn(svicp_ctx *ctx, const float *q_aos, int64_t n, int k, int *idx, float *d2)
+{
+    if (n == 0) return SVICP_OK;
+    HIPCHK(ctx->unresolved.reserve(sizeof(int) * n));
+    HIPCHK(ctx->n_unres.reserve(sizeof(int)));
+    HIPCHK(hipMemsetAsync(ctx->n_unres.p, 0, sizeof(int), ctx->stream));
+    const int grid = std::min(cdiv(n, kBlockThreads), 65536);
+    int *unres = ctx->unresolved.as<int>(), *nun = ctx->n_unres.as<int>();
+#define KNN_LAUNCH(KM)                                                                           \
+    do {                                                                                         \
+        hipLaunchKernelGGL((knn_kernel<KM, false>), dim3(grid), dim3(kBlockThreads), 0,          \
+                           ctx->stream, ctx->g, q_aos, (int)n, k, idx, d2, unres, nun);          \
+        LAUNCHCHK("knn_kernel");                                                                 \
+        hipLaunchKernelGGL((knn_kernel<KM, true>), dim3(std::min(grid, 1024)),                   \
+                           dim3(kBlockThreads), 0, ctx->stream, ctx->g, q_aos, (int)n, k, idx,   \
+                           d2, unres, nun);                                                      \
+        LAUNCHCHK("knn_kernel(brute)");                                                          \
+    } while (0)
+    if (k <= 8) KNN_LAUNCH(8);
+    else if (k <= 32) KNN_LAUNCH(32);
+    else KNN_LAUNCH(128);
+#undef KNN_LAUNCH
+    return SVICP_OK;
+}
+
+// 1-NN of the resident source into knn_idx / knn_d2 (caller order)
+int run_nn1(svicp_ctx *ctx, bool exact)
+{
+    const int64_t n = ctx->n;
+    HIPCHK(ctx->knn_idx.reserve(sizeof(int) * std::max<int64_t>(n, 1)));
+    HIPCHK(ctx->knn_d2.reserve(sizeof(float) * std::max<int64_t>(n, 1)));
+    if (n == 0) return SVICP_OK;
+    HIPCHK(ctx->unresolved.reserve(sizeof(int) * n));
+    HIPCHK(ctx->n_unres.reserve(sizeof(int)));
+    const float *x = ctx->cur ? ctx->wx.as<float>() : ctx->sx0.as<float>();
+    const float *y = ctx->cur ? ctx->wy.as<float>() : ctx->sy0.as<float>();
+    const float *z = ctx->cur ? ctx->wz.as<float>() : ctx->sz0.as<float>();
+    const int *perm = ctx->sorted ? ctx->perm.as<int>() : nullptr;
+    const int grid = std::min(cdiv(n, kBlockThreads), ctx->num_cus * 8);
+    if (!exact) {
+        hipLaunchKernelGGL((nn1_kernel<false>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
+                           ctx->g, x, y, z, perm, (int)n, ctx->opt.dist_threshold,
+                           ctx->knn_idx.as<int>(), ctx->knn_d2.as<float>(), (int *)nullptr,
+                           (int *)nullptr);
+        LAUNCHCHK("nn1_kernel");
+    } else {
+        HIPCHK(hipMemsetAsync(ctx->n_unres.p, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL((nn1_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
+                           ctx->g, x, y, z, perm, (int)n, ctx->opt.dist_threshold,
+                           ctx->knn_idx.as<int>(), ctx->knn_d2.as<float>(),
+                           ctx->unresolved.as<int>(), ctx->n_unres.as<int>());
+        LAUNCHCHK("nn1_kernel(exact)");
+        hipLaunchKernelGGL(nn1_brute_kernel, dim3(std::min<int64_t>(n, 2048)), dim3(kBlockThreads),
+                           0, ctx->stream, ctx->g, x, y, z, perm, ctx->unresolved.as<int>(),
+                           ctx->n_unres.as<int>(), ctx->knn_idx.as<int>(),
+                           ctx->knn_d2.as<float>());
+        LAUNCHCHK("nn1_brute_kernel");
+    }
+    return SVICP_OK;
+}
+
+int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
+{
+    const int64_t n = ctx->n;
+    int bpc = ctx->opt.blocks_per_cu > 0 ? ctx->opt.blocks_per_cu : 4;
+    int nb = std::max(1, std::min(cdiv(std::max<int64_t>(n, 1), kBlockThreads), ctx->num_cus * bpc));
+    int chunk = cdiv(cdiv(std::max<int64_t>(n, 1), nb), kBlockThreads) * kBlockThreads;
+    nb = std::max(1, cdiv(std::max<int64_t>(n, 1), chunk));
+    if (nb != ctx->nb || chunk != ctx->chunk) drop_graph(ctx);
+    ctx->nb = nb; ctx->chunk = chunk;
+    HIPCHK(ctx->partials.reserve(sizeof(double) * kNumSums * nb));
+    HIPCHK(ctx->state.reserve(sizeof(IcpState)));
+    if (iters > ctx->hist_cap) {
+        drop_graph(ctx);
+        int cap = std::max(iters, 64);
+        HIPCHK(ctx->xhist.reserve(sizeof(double) * 6 * cap));
+        HIPCHK(ctx->ihist.reserve(sizeof(double) * 4 * cap));
+        ctx->hist_cap = cap;
+    }
+    if (!ctx->h_state) HIPCHK(hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState), 0));
+    return SVICP_OK;
+}
+
+// launches one iteration's accumulate kernel; k = iteration number
+void launch_accumulate(svicp_ctx *ctx, int k, double *partials)
+{
+    const float *ix = (k <= 1) ? ctx->sx0.as<float>() : ctx->wx.as<float>();
+    const float *iy = (k <= 1) ? ctx->sy0.as<float>() : ctx->wy.as<float>();
+    const float *iz = (k <= 1) ? ctx->sz0.as<float>() : ctx->wz.as<float>();
+    if (k == 0)
+        hipLaunchKernelGGL((icp_accumulate_kernel<false>), dim3(ctx->nb), dim3(kBlockThreads), 0,
+                           ctx->stream, ctx->g, ix, iy, iz, (float *)nullptr, (float *)nullptr,
+                           (float *)nullptr, (int)ctx->n, ctx->chunk,
+                           ctx->state.as<IcpState>(), ctx->opt.dist_threshold, partials);
+    else
+        hipLaunchKernelGGL((icp_accumulate_kernel<true>), dim3(ctx->nb), dim3(kBlockThreads), 0,
+                           ctx->stream, ctx->g, ix, iy, iz, ctx->wx.as<float>(),
+                           ctx->wy.as<float>(), ctx->wz.as<float>(), (int)ctx->n, ctx->chunk,
+                           ctx->state.as<IcpState>(), ctx->opt.dist_threshold, partials);
+}
+
+int enqueue_loop(svicp_ctx *ctx, int iters, bool timed)
+{
+    hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(64), 0, ctx->stream,
+                       ctx->state.as<IcpState>());
+    LAUNCHCHK("reset_state_kernel");
+    for (int k = 0; k < iters; ++k) {
+        if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 0], ctx->stream));
+        launch_accumulate(ctx, k, ctx->partials.as<double>());
+        LAUNCHCHK("icp_accumulate_kernel");
+        if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 1], ctx->stream));
+        if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 2], ctx->stream));
+        hipLaunchKernelGGL(reduce_solve_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                           ctx->partials.as<double>(), ctx->nb, ctx->state.as<IcpState>(),
+                           ctx->xhist.as<double>(), ctx->ihist.as<double>(), k, (double *)nullptr);
+        LAUNCHCHK("reduce_solve_kernel");
+        if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 3], ctx->stream));
+    }
+    return SVICP_OK;
+}
+
+void fill_info(const svicp_ctx *ctx, int iters, svicp_info *info)
+{
+    if (!info) return;
+    const IcpState *s = ctx->h_state;
+    info->iterations = iters;
+    info->status = s->status;
+    info->inliers = s->S[27];
+    info->weighted_sq_residual = s->S[28];
+    info->weight_sum = s->S[29];
+    info->step_norm = s->S[30];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *svicp_last_error(const svicp_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int svicp_default_options(svicp_options *opt)
+{
+    if (!opt) return SVICP_ERR_ARG;
+    opt->dist_threshold = 5.0f;
+    opt->normals_k = 20;
+    opt->use_graph = 1;
+    opt->time_kernels = 0;
+    opt->sort_source = 1;
+    opt->blocks_per_cu = 4;
+    return SVICP_OK;
+}
+
+int svicp_create(int device_id, svicp_ctx **out)
+{
+    svicp_ctx *ctx = nullptr;
+    if (!out) return fail(nullptr, SVICP_ERR_ARG, "svicp_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, SVICP_ERR_NO_DEVICE, "svicp_create: no HIP device is visible");
+    if (device_id < 0 || device_id >= count)
+        return fail(nullptr, SVICP_ERR_ARG, "svicp_create: device_id out of range");
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return fail(nullptr, SVICP_ERR_HIP, "hipSetDevice", e);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return fail(nullptr, SVICP_ERR_HIP, "hipGetDeviceProperties", e);
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string msg = std::string("svicp_create: device is ") + prop.gcnArchName +
+                          ", the library holds gfx950 code only";
+        return fail(nullptr, SVICP_ERR_NO_DEVICE, msg.c_str());
+    }
+    ctx = new svicp_ctx();
+    ctx->device = device_id;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    svicp_default_options(&ctx->opt);
+    e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail(nullptr, SVICP_ERR_HIP, "hipStreamCreate", e); }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return SVICP_OK;
+}
+
+int svicp_destroy(svicp_ctx *ctx)
+{
+    if (!ctx) return SVICP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    drop_graph(ctx);
+    for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    DevBuf *bufs[] = { &ctx->tgt_aos, &ctx->nrm_aos, &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->run2,
+                       &ctx->end1, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx, &ctx->wy, &ctx->wz,
+                       &ctx->perm, &ctx->tmp_aos, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
+                       &ctx->vals_b, &ctx->marks, &ctx->ranks, &ctx->block_of_rank,
+                       &ctx->sort_tmp, &ctx->bbox6, &ctx->knn_idx, &ctx->knn_d2,
+                       &ctx->unresolved, &ctx->n_unres, &ctx->partials, &ctx->state, &ctx->xhist,
+                       &ctx->ihist };
+    for (DevBuf *b : bufs) b->release();
+    if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return SVICP_OK;
+}
+
+int svicp_set_options(svicp_ctx *ctx, const svicp_options *opt)
+{
+    if (!ctx || !opt) return fail(ctx, SVICP_ERR_ARG, "svicp_set_options: NULL argument");
+    if (!(opt->dist_threshold > 0.f) || !std::isfinite(opt->dist_threshold))
+        return fail(ctx, SVICP_ERR_ARG, "svicp_set_options: dist_threshold must be positive");
+    if (opt->normals_k < 3 || opt->normals_k > 128)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_set_options: normals_k must be in [3, 128]");
+    if (ctx->have_target && opt->dist_threshold != ctx->opt.dist_threshold)
+        return fail(ctx, SVICP_ERR_ARG,
+                    "svicp_set_options: dist_threshold sizes the grid; set it before the target");
+    ctx->opt = *opt;
+    drop_graph(ctx);
+    return SVICP_OK;
+}
+
+int svicp_get_options(const svicp_ctx *ctx, svicp_options *opt)
+{
+    if (!ctx || !opt) return SVICP_ERR_ARG;
+    *opt = ctx->opt;
+    return SVICP_OK;
+}
+
+int svicp_sizes(const svicp_ctx *ctx, int64_t *m, int64_t *n)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (m) *m = ctx->have_target ? ctx->m : 0;
+    if (n) *n = ctx->have_source ? ctx->n : 0;
+    return SVICP_OK;
+}
+
+int svicp_set_stream(svicp_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = (hipStream_t)hip_stream;   // NULL is the default stream
+    drop_graph(ctx);
+    return SVICP_OK;
+}
+
+int svicp_use_own_stream(svicp_ctx *ctx)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
+    drop_graph(ctx);
+    return SVICP_OK;
+}
+
+int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const float *normals_aos)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (m < 0 || (m > 0 && !xyz_aos))
+        return fail(ctx, SVICP_ERR_ARG, "svicp_set_target: bad cloud pointer or size");
+    if (m > (int64_t)0x7fffff00)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_set_target: more than 2^31 points");
+    HIPCHK(hipSetDevice(ctx->device));
+    drop_graph(ctx);
+    ctx->have_target = false;
+    ctx->m = m;
+    const int64_t mm = std::max<int64_t>(m, 1);
+
+    HIPCHK(ctx->tgt_aos.reserve(sizeof(float) * 3 * mm));
+    HIPCHK(ctx->nrm_aos.reserve(sizeof(float) * 3 * mm));
+    HIPCHK(ctx->pts.reserve(sizeof(float4) * mm));
+    HIPCHK(ctx->nrm.reserve(sizeof(float) * 3 * mm));
+    if (m > 0)
+        HIPCHK(hipMemcpyAsync(ctx->tgt_aos.p, xyz_aos, sizeof(float) * 3 * m, hipMemcpyHostToDevice,
+                              ctx->stream));
+
+    // ---- grid geometry ----
+    float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
+    if (m > 0) {
+        int rc = device_bbox(ctx, ctx->tgt_aos.as<float>(), m, mn, mx);
+        if (rc) return rc;
+        for (int a = 0; a < 3; ++a)
+            if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]))
+                return fail(ctx, SVICP_ERR_ARG, "svicp_set_target: non-finite coordinates");
+    }
+    float maxabs = 0.f;
+    for (int a = 0; a < 3; ++a) maxabs = std::max(maxabs, std::max(std::fabs(mn[a]), std::fabs(mx[a])));
+    const float r = std::sqrt(ctx->opt.dist_threshold);
+    const float eps_abs = maxabs * (1.0f / 1048576.0f);
+    GridDesc g{};
+    g.rr = r * 1.002f + eps_abs;
+    float h = 2.0f * g.rr * 1.02f + 4.0f * eps_abs;
+    long long nbt = 0;
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        long long nn[3];
+        bool fits = true;
+        for (int a = 0; a < 3; ++a) {
+            float o = mn[a] - 1.5f * h;
+            nn[a] = (long long)std::floor((double)(mx[a] - o) / (double)h) + 3;
+            if (nn[a] > 32768) fits = false;
+        }
+        nbt = ((nn[0] + 3) / 4) * ((nn[1] + 3) / 4) * ((nn[2] + 3) / 4);
+        if (nbt > (1ll << 28)) fits = false;
+        if (fits) {
+            g.ox = mn[0] - 1.5f * h; g.oy = mn[1] - 1.5f * h; g.oz = mn[2] - 1.5f * h;
+            g.nx = (int)nn[0]; g.ny = (int)nn[1]; g.nz = (int)nn[2];
+            break;
+        }
+        h *= 1.5f;   // coarser cells stay exact, they only hold more candidates
+        if (attempt == 63) return fail(ctx, SVICP_ERR_GRID, "svicp_set_target: extent too large for the grid");
+    }
+    g.h = h; g.inv_h = 1.0f / h;
+    g.nbx = (g.nx + 3) / 4; g.nby = (g.ny + 3) / 4; g.nbz = (g.nz + 3) / 4;
+    g.fnx1 = (float)(g.nx - 1); g.fny1 = (float)(g.ny - 1); g.fnz1 = (float)(g.nz - 1);
+    g.cov_slack = 8.0f * (maxabs + h * (float)std::max(g.nx, std::max(g.ny, g.nz))) * (1.0f / 8388608.0f);
+    g.m = (int)m;
+    nbt = (long long)g.nbx * g.nby * g.nbz;
+
+    // ---- sort by cell key ----
+    HIPCHK(ctx->keys_a.reserve(sizeof(unsigned long long) * mm));
+    HIPCHK(ctx->vals_a.reserve(sizeof(int) * mm));
+    HIPCHK(ctx->marks.reserve(sizeof(int) * nbt));
+    HIPCHK(ctx->ranks.reserve(sizeof(int) * nbt));
+    HIPCHK(ctx->dir.reserve(sizeof(int) * nbt));
+    HIPCHK(ctx->block_of_rank.reserve(sizeof(int) * std::min<long long>(nbt, 2 * mm)));
+    HIPCHK(hipMemsetAsync(ctx->marks.p, 0, sizeof(int) * nbt, ctx->stream));
+    int nranked = 0;
+    if (m > 0) {
+        hipLaunchKernelGGL(cell_key_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, g,
+                           ctx->tgt_aos.as<float>(), (int)m, ctx->keys_a.as<unsigned long long>(),
+                           ctx->vals_a.as<int>());
+        LAUNCHCHK("cell_key_kernel");
+        unsigned long long ncell = (unsigned long long)g.nx * g.ny * g.nz;
+        int bits = 1;
+        while (bits < 64 && (ncell >> bits)) ++bits;
+        int rc = sort_pairs(ctx, m, bits);
+        if (rc) return rc;
+        hipLaunchKernelGGL(mark_blocks_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, g,
+                           ctx->keys_b.as<unsigned long long>(), (int)m, ctx->marks.as<int>());
+        LAUNCHCHK("mark_blocks_kernel");
+    }
+    {
+        size_t bytes = 0;
+        HIPCHK(rocprim::exclusive_scan(nullptr, bytes, ctx->marks.as<int>(), ctx->ranks.as<int>(), 0,
+                                       (size_t)nbt, rocprim::plus<int>(), ctx->stream));
+        HIPCHK(ctx->sort_tmp.reserve(bytes));
+        HIPCHK(rocprim::exclusive_scan(ctx->sort_tmp.p, bytes, ctx->marks.as<int>(),
+                                       ctx->ranks.as<int>(), 0, (size_t)nbt, rocprim::plus<int>(),
+                                       ctx->stream));
+        int last_rank = 0, last_mark = 0;
+        HIPCHK(hipMemcpyAsync(&last_rank, ctx->ranks.as<int>() + (nbt - 1), sizeof(int),
+                              hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&last_mark, ctx->marks.as<int>() + (nbt - 1), sizeof(int),
+                              hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        nranked = last_rank + last_mark;
+    }
+    ctx->nranked = nranked;
+    hipLaunchKernelGGL(finish_dir_kernel, dim3(cdiv(nbt, 256)), dim3(256), 0, ctx->stream,
+                       ctx->marks.as<int>(), ctx->ranks.as<int>(), (int)nbt, ctx->dir.as<int>(),
+                       ctx->block_of_rank.as<int>());
+    LAUNCHCHK("finish_dir_kernel");
+    HIPCHK(ctx->run2.reserve(sizeof(uint2) * 64 * std::max(nranked, 1)));
+    HIPCHK(ctx->end1.reserve(sizeof(unsigned) * 64 * std::max(nranked, 1)));
+    if (nranked > 0) {
+        hipLaunchKernelGGL(fill_cells_kernel, dim3(cdiv((long long)nranked * 64, 256)), dim3(256), 0,
+                           ctx->stream, g, ctx->keys_b.as<unsigned long long>(), (int)m,
+                           ctx->block_of_rank.as<int>(), nranked, ctx->run2.as<uint2>(),
+                           ctx->end1.as<unsigned>());
+        LAUNCHCHK("fill_cells_kernel");
+    }
+    g.dir = ctx->dir.as<int>();
+    g.run2 = ctx->run2.as<uint2>();
+    g.end1 = ctx->end1.as<unsigned>();
+    g.pts = ctx->pts.as<float4>();
+    g.nrm = ctx->nrm.as<float>();
+    ctx->g = g;
+
+    if (m > 0) {
+        hipLaunchKernelGGL(gather_target_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream,
+                           ctx->tgt_aos.as<float>(), (const float *)nullptr, ctx->vals_b.as<int>(),
+                           (int)m, ctx->pts.as<float4>(), ctx->nrm.as<float>());
+        LAUNCHCHK("gather_target_kernel");
+        // ---- normals ----
+        if (normals_aos) {
+            HIPCHK(hipMemcpyAsync(ctx->nrm_aos.p, normals_aos, sizeof(float) * 3 * m,
+                                  hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            const int k = ctx->opt.normals_k;
+            HIPCHK(ctx->knn_idx.reserve(sizeof(int) * m * k));
+            HIPCHK(ctx->knn_d2.reserve(sizeof(float) * m * k));
+            int rc = run_knn(ctx, ctx->tgt_aos.as<float>(), m, k, ctx->knn_idx.as<int>(),
+                             ctx->knn_d2.as<float>());
+            if (rc) return rc;
+            hipLaunchKernelGGL(normals_kernel, dim3(cdiv(m, kBlockThreads)), dim3(kBlockThreads), 0,
+                               ctx->stream, ctx->tgt_aos.as<float>(), ctx->knn_idx.as<int>(), (int)m,
+                               k, ctx->nrm_aos.as<float>());
+            LAUNCHCHK("normals_kernel");
+        }
+        hipLaunchKernelGGL(gather_target_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream,
+                           ctx->tgt_aos.as<float>(), ctx->nrm_aos.as<float>(), ctx->vals_b.as<int>(),
+                           (int)m, ctx->pts.as<float4>(), ctx->nrm.as<float>());
+        LAUNCHCHK("gather_target_kernel(normals)");
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->have_target = true;
+    return SVICP_OK;
+}
+
+int svicp_get_normals(svicp_ctx *ctx, float *normals_aos_out)
+{
+    if (!ctx || !normals_aos_out) return fail(ctx, SVICP_ERR_ARG, "svicp_get_normals: NULL argument");
+    if (!ctx->have_target) return fail(ctx, SVICP_ERR_ARG, "svicp_get_normals: no target set");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->m > 0)
+        HIPCHK(hipMemcpyAsync(normals_aos_out, ctx->nrm_aos.p, sizeof(float) * 3 * ctx->m,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SVICP_OK;
+}
+
+int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (n < 0 || (n > 0 && !xyz_aos))
+        return fail(ctx, SVICP_ERR_ARG, "svicp_set_source: bad cloud pointer or size");
+    if (n > (int64_t)0x7fffff00)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_set_source: more than 2^31 points");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n != ctx->n) drop_graph(ctx);
+    ctx->have_source = false;
+    const int64_t nn = std::max<int64_t>(n, 1);
+    DevBuf *soa[] = { &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx, &ctx->wy, &ctx->wz };
+    for (DevBuf *b : soa) {
+        void *before = b->p;
+        HIPCHK(b->reserve(sizeof(float) * nn));
+        if (b->p != before) drop_graph(ctx);
+    }
+    HIPCHK(ctx->tmp_aos.reserve(sizeof(float) * 3 * nn));
+    ctx->n = n;
+    ctx->cur = 0;
+    ctx->sorted = false;
+    if (n > 0) {
+        HIPCHK(hipMemcpyAsync(ctx->tmp_aos.p, xyz_aos, sizeof(float) * 3 * n, hipMemcpyHostToDevice,
+                              ctx->stream));
+        const int *perm = nullptr;
+        if (ctx->opt.sort_source && n > 1) {
+            float mn[3], mx[3];
+            int rc = device_bbox(ctx, ctx->tmp_aos.as<float>(), n, mn, mx);
+            if (rc) return rc;
+            float ext = 0.f;
+            for (int a = 0; a < 3; ++a) ext = std::max(ext, mx[a] - mn[a]);
+            if (std::isfinite(ext) && ext > 0.f) {
+                HIPCHK(ctx->keys_a.reserve(sizeof(unsigned long long) * nn));
+                HIPCHK(ctx->vals_a.reserve(sizeof(int) * nn));
+                hipLaunchKernelGGL(morton_key_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
+                                   ctx->tmp_aos.as<float>(), (int)n, mn[0], mn[1], mn[2],
+                                   2097151.0f / ext, ctx->keys_a.as<unsigned long long>(),
+                                   ctx->vals_a.as<int>());
+                LAUNCHCHK("morton_key_kernel");
+                rc = sort_pairs(ctx, n, 63);
+                if (rc) return rc;
+                void *before = ctx->perm.p;
+                HIPCHK(ctx->perm.reserve(sizeof(int) * nn));
+                if (ctx->perm.p != before) drop_graph(ctx);
+                HIPCHK(hipMemcpyAsync(ctx->perm.p, ctx->vals_b.p, sizeof(int) * n,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+                perm = ctx->perm.as<int>();
+                ctx->sorted = true;
+            }
+        }
+        hipLaunchKernelGGL(aos_to_soa_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
+                           ctx->tmp_aos.as<float>(), perm, (int)n, ctx->sx0.as<float>(),
+                           ctx->sy0.as<float>(), ctx->sz0.as<float>());
+        LAUNCHCHK("aos_to_soa_kernel");
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->have_source = true;
+    return SVICP_OK;
+}
+
+int svicp_get_source(svicp_ctx *ctx, float *xyz_aos_out)
+{
+    if (!ctx || !xyz_aos_out) return fail(ctx, SVICP_ERR_ARG, "svicp_get_source: NULL argument");
+    if (!ctx->have_source) return fail(ctx, SVICP_ERR_ARG, "svicp_get_source: no source set");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    if (n > 0) {
+        const float *x = ctx->cur ? ctx->wx.as<float>() : ctx->sx0.as<float>();
+        const float *y = ctx->cur ? ctx->wy.as<float>() : ctx->sy0.as<float>();
+        const float *z = ctx->cur ? ctx->wz.as<float>() : ctx->sz0.as<float>();
+        hipLaunchKernelGGL(soa_to_aos_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, x, y, z,
+                           ctx->sorted ? ctx->perm.as<int>() : (const int *)nullptr, (int)n,
+                           ctx->tmp_aos.as<float>());
+        LAUNCHCHK("soa_to_aos_kernel");
+        HIPCHK(hipMemcpyAsync(xyz_aos_out, ctx->tmp_aos.p, sizeof(float) * 3 * n,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SVICP_OK;
+}
+
+int svicp_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (iterations < 1 || !T_out)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_run: iterations must be >= 1 and T_out non-NULL");
+    if (!ctx->have_target || !ctx->have_source)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_run: set the target and the source first");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_iteration_buffers(ctx, iterations);
+    if (rc) return rc;
+
+    const bool timed = ctx->opt.time_kernels != 0;
+    if (timed) {
+        while ((int)ctx->events.size() < 4 * iterations) {
+            hipEvent_t ev;
+            HIPCHK(hipEventCreate(&ev));
+            ctx->events.push_back(ev);
+        }
+    }
+    if (ctx->opt.use_graph && !timed) {
+        if (!ctx->gexec || ctx->g_iters != iterations) {
+            drop_graph(ctx);
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_loop(ctx, iterations, false);
+            hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (e != hipSuccess) return fail(ctx, SVICP_ERR_HIP, "hipStreamEndCapture", e);
+            e = hipGraphInstantiate(&ctx->gexec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { ctx->gexec = nullptr; return fail(ctx, SVICP_ERR_HIP, "hipGraphInstantiate", e); }
+            ctx->g_iters = iterations;
+        }
+        HIPCHK(hipGraphLaunch(ctx->gexec, ctx->stream));
+    } else {
+        rc = enqueue_loop(ctx, iterations, timed);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->state.p, sizeof(IcpState), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->cur = iterations > 1 ? 1 : 0;
+    ctx->last_iters = iterations;
+    std::memcpy(T_out, ctx->h_state->Trans, sizeof(double) * 16);
+    fill_info(ctx, iterations, info);
+
+    if (timed) {
+        double fa = 0, so = 0;
+        for (int k = 0; k < iterations; ++k) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ctx->events[4 * k + 0], ctx->events[4 * k + 1]));
+            fa += ms;
+            HIPCHK(hipEventElapsedTime(&ms, ctx->events[4 * k + 2], ctx->events[4 * k + 3]));
+            so += ms;
+        }
+        ctx->fused_ms = fa / iterations;
+        ctx->solve_ms = so / iterations;
+        ctx->timed_launches = iterations;
+    }
+    if (ctx->h_state->status == SVICP_ERR_SINGULAR)
+        return fail(ctx, SVICP_ERR_SINGULAR, "svicp_run: normal matrix not positive definite (too few correspondences?)");
+    return SVICP_OK;
+}
+
+int svicp_get_history(svicp_ctx *ctx, double *X_out, double *info_out)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (ctx->last_iters <= 0) return fail(ctx, SVICP_ERR_ARG, "svicp_get_history: no run yet");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (X_out)
+        HIPCHK(hipMemcpyAsync(X_out, ctx->xhist.p, sizeof(double) * 6 * ctx->last_iters,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    if (info_out)
+        HIPCHK(hipMemcpyAsync(info_out, ctx->ihist.p, sizeof(double) * 4 * ctx->last_iters,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SVICP_OK;
+}
+
+int svicp_correspondences(svicp_ctx *ctx, int32_t *idx_out, float *d2_out)
+{
+    if (!ctx || !idx_out || !d2_out)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_correspondences: NULL argument");
+    if (!ctx->have_target || !ctx->have_source)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_correspondences: set the target and the source first");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = run_nn1(ctx, false);
+    if (rc) return rc;
+    if (ctx->n > 0) {
+        HIPCHK(hipMemcpyAsync(idx_out, ctx->knn_idx.p, sizeof(int) * ctx->n, hipMemcpyDeviceToHost,
+                              ctx->stream));
+        HIPCHK(hipMemcpyAsync(d2_out, ctx->knn_d2.p, sizeof(float) * ctx->n, hipMemcpyDeviceToHost,
+                              ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SVICP_OK;
+}
+
+int svicp_knn(svicp_ctx *ctx, const float *query_aos, int64_t n, int k, int32_t *idx_out,
+              float *d2_out)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (n < 0 || k < 1 || (n > 0 && (!query_aos || !idx_out || !d2_out)))
+        return fail(ctx, SVICP_ERR_ARG, "svicp_knn: bad argument");
+    if (!ctx->have_target) return fail(ctx, SVICP_ERR_ARG, "svicp_knn: no target set");
+    if (k > 128) k = 128;   // CKNNSearch::setKCount clamps the same way
+    if (n == 0) return SVICP_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(ctx->tmp_aos.reserve(sizeof(float) * 3 * n));
+    HIPCHK(ctx->knn_idx.reserve(sizeof(int) * n * k));
+    HIPCHK(ctx->knn_d2.reserve(sizeof(float) * n * k));
+    HIPCHK(hipMemcpyAsync(ctx->tmp_aos.p, query_aos, sizeof(float) * 3 * n, hipMemcpyHostToDevice,
+                          ctx->stream));
+    int rc = run_knn(ctx, ctx->tmp_aos.as<float>(), n, k, ctx->knn_idx.as<int>(),
+                     ctx->knn_d2.as<float>());
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(idx_out, ctx->knn_idx.p, sizeof(int) * n * k, hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipMemcpyAsync(d2_out, ctx->knn_d2.p, sizeof(float) * n * k, hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SVICP_OK;
+}
+
+int svicp_shard_begin(svicp_ctx *ctx)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (!ctx->have_target || !ctx->have_source)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_shard_begin: set the target and the source first");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_iteration_buffers(ctx, 64);
+    if (rc) return rc;
+    hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(64), 0, ctx->stream,
+                       ctx->state.as<IcpState>());
+    LAUNCHCHK("reset_state_kernel");
+    ctx->shard_iter = 0;
+    ctx->cur = 0;
+    return SVICP_OK;
+}
+
+int svicp_shard_accumulate(svicp_ctx *ctx, double *dev_partial32)
+{
+    if (!ctx || !dev_partial32) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_accumulate: NULL argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_iteration_buffers(ctx, ctx->shard_iter + 1);
+    if (rc) return rc;
+    launch_accumulate(ctx, ctx->shard_iter, ctx->partials.as<double>());
+    LAUNCHCHK("icp_accumulate_kernel");
+    hipLaunchKernelGGL(reduce_solve_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                       ctx->partials.as<double>(), ctx->nb, ctx->state.as<IcpState>(),
+                       (double *)nullptr, (double *)nullptr, ctx->shard_iter, dev_partial32);
+    LAUNCHCHK("reduce_solve_kernel(partial)");
+    if (ctx->shard_iter >= 1) ctx->cur = 1;
+    return SVICP_OK;
+}
+
+int svicp_shard_update(svicp_ctx *ctx, const double *dev_sum32)
+{
+    if (!ctx || !dev_sum32) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_update: NULL argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(solve_from_sums_kernel, dim3(1), dim3(64), 0, ctx->stream, dev_sum32,
+                       ctx->state.as<IcpState>(), ctx->xhist.as<double>(), ctx->ihist.as<double>(),
+                       ctx->shard_iter);
+    LAUNCHCHK("solve_from_sums_kernel");
+    ctx->shard_iter++;
+    ctx->last_iters = ctx->shard_iter;
+    return SVICP_OK;
+}
+
+int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info)
+{
+    if (!ctx || !T_out) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_finish: NULL argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->state.p, sizeof(IcpState), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::memcpy(T_out, ctx->h_state->Trans, sizeof(double) * 16);
+    fill_info(ctx, ctx->shard_iter, info);
+    if (ctx->h_state->status == SVICP_ERR_SINGULAR)
+        return fail(ctx, SVICP_ERR_SINGULAR, "svicp_shard_finish: normal matrix not positive definite");
+    return SVICP_OK;
+}
+
+int svicp_kernel_times(svicp_ctx *ctx, double *fused_ms, double *solve_ms, int *launches)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (fused_ms) *fused_ms = ctx->fused_ms;
+    if (solve_ms) *solve_ms = ctx->solve_ms;
+    if (launches) *launches = ctx->timed_launches;
+    return SVICP_OK;
+}
+
+int svicp_time_nn(svicp_ctx *ctx, int exact, int reps, double *avg_ms)
+{
+    if (!ctx || !avg_ms || reps < 1) return fail(ctx, SVICP_ERR_ARG, "svicp_time_nn: bad argument");
+    if (!ctx->have_target || !ctx->have_source)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_time_nn: set the target and the source first");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    int rc = run_nn1(ctx, exact != 0);   // warm-up
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(a, ctx->stream));
+    for (int r = 0; r < reps; ++r) {
+        rc = run_nn1(ctx, exact != 0);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(b, ctx->stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *avg_ms = (double)ms / reps;
+    return SVICP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,286 @@
+"""Host-side mirror of the reference's registration interface over the C ABI.
+
+`Context` is a thin object wrapper of one svicp_ctx.  `CPoint2PlaneICP`,
+`CKNNSearch` and `CTxtReader` keep the reference's method names, argument
+meaning and side effects (PointCloud/Registration/CPoint2PlaneICP.h:11-17,
+CKNNSearch.h:12-17, CTxtReader.h:6-13); a cloud is an (N, 3) float32 numpy
+array where the reference passes a flann::Matrix<float> view.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Info, Options, SvicpError
+
+
+def _cloud(a, name):
+    a = np.asarray(a)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError(f"{name}: expected an (N, 3) array, got shape {a.shape}")
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context:
+    """One svicp_ctx: a target grid, a resident source and the iteration state."""
+
+    def __init__(self, device=0, **options):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        rc = self._lib.svicp_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise SvicpError(rc, self._lib.svicp_last_error(None).decode())
+        if options:
+            self.set_options(**options)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SvicpError(rc, self._lib.svicp_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.svicp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- options --
+    def options(self):
+        o = Options()
+        self._check(self._lib.svicp_get_options(self._h, C.byref(o)))
+        return o
+
+    def set_options(self, **kw):
+        o = self.options()
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k!r}")
+            setattr(o, k, v)
+        self._check(self._lib.svicp_set_options(self._h, C.byref(o)))
+
+    # -- clouds --
+    def set_target(self, xyz, normals=None):
+        xyz = _cloud(xyz, "target")
+        if normals is not None:
+            normals = _cloud(normals, "normals")
+            if normals.shape != xyz.shape:
+                raise ValueError("normals must match the target's shape")
+        self._check(self._lib.svicp_set_target(
+            self._h, _fp(xyz), xyz.shape[0], _fp(normals) if normals is not None else None))
+
+    def get_normals(self):
+        m, _ = self.sizes()
+        out = np.empty((m, 3), np.float32)
+        self._check(self._lib.svicp_get_normals(self._h, _fp(out)))
+        return out
+
+    def set_source(self, xyz):
+        xyz = _cloud(xyz, "source")
+        self._check(self._lib.svicp_set_source(self._h, _fp(xyz), xyz.shape[0]))
+
+    def get_source(self, out=None):
+        _, n = self.sizes()
+        if out is None:
+            out = np.empty((n, 3), np.float32)
+        assert out.dtype == np.float32 and out.shape == (n, 3) and out.flags.c_contiguous
+        self._check(self._lib.svicp_get_source(self._h, _fp(out)))
+        return out
+
+    def sizes(self):
+        m, n = C.c_int64(), C.c_int64()
+        self._check(self._lib.svicp_sizes(self._h, C.byref(m), C.byref(n)))
+        return m.value, n.value
+
+    # -- registration --
+    def run(self, iterations):
+        """Returns (4x4 transform, Info)."""
+        T = np.empty(16, np.float64)
+        info = Info()
+        self._iters = int(iterations)
+        self._check(self._lib.svicp_run(self._h, int(iterations), _dp(T), C.byref(info)))
+        return T.reshape(4, 4), info
+
+    def history(self):
+        """Per-iteration X (iters x 6) and {inliers, sum w b^2, |X|, sum w} (iters x 4)."""
+        iters = getattr(self, "_iters", 0)
+        X = np.empty((iters, 6), np.float64)
+        I = np.empty((iters, 4), np.float64)
+        self._check(self._lib.svicp_get_history(self._h, _dp(X), _dp(I)))
+        return X, I
+
+    def correspondences(self):
+        _, n = self.sizes()
+        idx = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        self._check(self._lib.svicp_correspondences(self._h, _ip(idx), _fp(d2)))
+        return idx, d2
+
+    def knn(self, query, k=1):
+        q = _cloud(query, "query")
+        k = min(int(k), 128)
+        idx = np.empty((q.shape[0], k), np.int32)
+        d2 = np.empty((q.shape[0], k), np.float32)
+        self._check(self._lib.svicp_knn(self._h, _fp(q), q.shape[0], k, _ip(idx), _fp(d2)))
+        return idx, d2
+
+    # -- sharded stepping --
+    def set_stream(self, stream_handle):
+        """Launch on this hipStream_t from now on (0 is the default stream)."""
+        self._check(self._lib.svicp_set_stream(self._h, C.c_void_p(int(stream_handle))))
+
+    def use_own_stream(self):
+        self._check(self._lib.svicp_use_own_stream(self._h))
+
+    def shard_begin(self):
+        self._check(self._lib.svicp_shard_begin(self._h))
+
+    def shard_accumulate(self, dev_ptr):
+        self._check(self._lib.svicp_shard_accumulate(self._h, C.c_void_p(dev_ptr)))
+
+    def shard_update(self, dev_ptr):
+        self._check(self._lib.svicp_shard_update(self._h, C.c_void_p(dev_ptr)))
+
+    def shard_finish(self):
+        T = np.empty(16, np.float64)
+        info = Info()
+        self._check(self._lib.svicp_shard_finish(self._h, _dp(T), C.byref(info)))
+        return T.reshape(4, 4), info
+
+    # -- measurement --
+    def kernel_times(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_int()
+        self._check(self._lib.svicp_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def time_nn(self, exact=False, reps=10):
+        ms = C.c_double()
+        self._check(self._lib.svicp_time_nn(self._h, 1 if exact else 0, int(reps), C.byref(ms)))
+        return ms.value
+
+
+class CKNNSearch:
+    """CKNNSearch (CKNNSearch.h:9-25): exact k-NN, squared fp32 distances."""
+
+    def __init__(self, device=0):
+        self._ctx = Context(device)
+        self.m_k = 1                       # CKNNSearch.cpp:5
+        self._query = None
+
+    def setTreeData(self, data):
+        self._ctx.set_target(data, normals=np.zeros_like(_cloud(data, "data")))
+
+    def setQueryData(self, querydata):
+        self._query = _cloud(querydata, "querydata")
+
+    def setKCount(self, count):
+        self.m_k = 128 if count > 128 else int(count)   # CKNNSearch.cpp:60-65
+
+    def getKNeighbour(self):
+        """Returns (indices N x k int32, squared distances N x k float32)."""
+        if self._query is None:
+            raise SvicpError(_lib.ERR_ARG, "getKNeighbour: setQueryData was not called")
+        return self._ctx.knn(self._query, self.m_k)
+
+
+class CPoint2PlaneICP:
+    """CPoint2PlaneICP (CPoint2PlaneICP.h:8-27).
+
+    run() transforms the caller's move array in place (count - 1 times), as the
+    reference does to the buffer behind its flann::Matrix view, and prints the
+    accumulated transform.  getTransform()/getInfo() are additions: the
+    reference only prints.
+    """
+
+    def __init__(self, device=0, verbose=True):
+        self._ctx = Context(device)
+        self.m_count = 1
+        self.m_eps = 0.0
+        self._move = None
+        self._T = None
+        self._info = None
+        self._verbose = verbose
+
+    def setReferenceData(self, ref, normals=None):
+        self._ctx.set_target(ref, normals)
+
+    def setMoveData(self, move):
+        if not (isinstance(move, np.ndarray) and move.dtype == np.float32
+                and move.ndim == 2 and move.shape[1] == 3 and move.flags.c_contiguous):
+            raise ValueError("setMoveData: pass a C-contiguous (N, 3) float32 array; "
+                             "run() updates it in place")
+        self._move = move
+
+    def setEpsilon(self, eps):
+        self.m_eps = float(eps)            # stored and never read, as in the reference
+
+    def setMaxIterateCount(self, count):
+        self.m_count = int(count)
+
+    def run(self):
+        if self._move is None:
+            raise SvicpError(_lib.ERR_ARG, "run: setMoveData was not called")
+        self._ctx.set_source(self._move)
+        self._T, self._info = self._ctx.run(self.m_count)
+        self._ctx.get_source(self._move)
+        if self._verbose:
+            print("Current Transformation:")
+            print(self._T)
+
+    def getTransform(self):
+        return self._T
+
+    def getInfo(self):
+        return self._info
+
+    def getNormals(self):
+        return self._ctx.get_normals()
+
+
+class CTxtReader:
+    """CTxtReader (CTxtReader.cpp:13-61): space-separated floats, three per row."""
+
+    def read(self, path):
+        vals = []
+        try:
+            f = open(path, "r")
+        except OSError:
+            return np.empty((0, 3), np.float32)   # the reference returns an empty view
+        with f:
+            for line in f:
+                for tok in line.rstrip("\n").split(" "):
+                    if tok:
+                        vals.append(_atof(tok))
+        rows = len(vals) // 3
+        return np.asarray(vals[: rows * 3], dtype=np.float64).astype(np.float32).reshape(rows, 3)
+
+
+def _atof(tok):
+    """C atof: the longest numeric prefix, 0.0 when there is none."""
+    try:
+        return float(tok)
+    except ValueError:
+        import re
+        m = re.match(r"\s*[-+]?(\d+\.?\d*([eE][-+]?\d+)?|\.\d+([eE][-+]?\d+)?|inf(inity)?|nan)", tok, re.I)
+        return float(m.group(0)) if m else 0.0

@@ -1,0 +1,291 @@
+"""GPU parity tests: the HIP path through the C ABI against the CPU oracle and
+the golden vectors.  Integer results (correspondence indices, k-NN lists) and
+fp32 distances must be bit-exact; the transform must agree within 1e-6 in
+rotation (radians) and 1e-6 * extent in translation, the tolerance the
+specification of this path states.  In practice agreement is ~1e-10."""
+import numpy as np
+import pytest
+
+import refmath
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL = 1e-6
+X_TOL = 1e-8
+
+
+def _check_transform(T, T_ref, extent):
+    assert refmath.rot_angle(T[:3, :3], T_ref[:3, :3]) < ROT_TOL
+    assert np.abs(T[:3, 3] - T_ref[:3, 3]).max() < 1e-6 * extent
+    assert np.array_equal(T[3], [0, 0, 0, 1])
+
+
+def _extent(cloud):
+    return float((cloud.max(0) - cloud.min(0)).max())
+
+
+# ---------------------------------------------------------------- bundled pair
+def test_normals_match_oracle(ctx, pair):
+    ref, _, gold = pair
+    ctx.set_target(ref)
+    n = ctx.get_normals()
+    sign = np.sign((n * gold["normals"]).sum(1))[:, None]
+    assert np.abs(n * sign - gold["normals"]).max() <= 1.2e-7      # one fp32 ulp of a unit vector
+    assert (np.abs((n * gold["normals"]).sum(1)) > 0.999999).all()
+
+
+def test_knn_bit_exact_on_bundled_pair(ctx, pair, po):
+    ref, src, gold = pair
+    ctx.set_target(ref, gold["normals"])
+    idx, d2 = ctx.knn(src, 1)
+    assert np.array_equal(idx[:, 0], gold["nn_idx"]) and np.array_equal(d2[:, 0], gold["nn_d2"])
+    tree = po.KDTree(ref)
+    for k in (2, 20, 33):
+        gi, gd = ctx.knn(ref, k)
+        oi, od = tree.knn(ref, k)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    assert np.array_equal(ctx.knn(ref, 20)[0][:64], gold["knn20_head"])
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_icp_5_iterations_as_test_cpp(ctx, pair, graph):
+    ref, src, gold = pair
+    ctx.set_options(use_graph=graph)
+    ctx.set_target(ref)                       # normals estimated on the device
+    ctx.set_source(src)
+    T, info = ctx.run(5)                      # test.cpp:23
+    X, I = ctx.history()
+    _check_transform(T, gold["trans5"], _extent(ref))
+    assert np.abs(X - gold["X5"]).max() < X_TOL
+    assert info.iterations == 5 and info.status == 0
+    assert info.inliers == gold["info5"][-1, 0]
+    assert np.allclose(I[:, 0], gold["info5"][:, 0])
+    assert np.allclose(I[:, 1], gold["info5"][:, 1], rtol=1e-6, atol=1e-9)
+    # the source is left transformed count-1 times (CPoint2PlaneICP.cpp:42-50)
+    out = ctx.get_source()
+    assert np.abs(out - gold["src5"]).max() <= 4e-5          # a few fp32 ulps at |x| ~ 250
+    assert (out == gold["src5"]).mean() > 0.99
+    T30, _ = ctx.run(30)
+    _check_transform(T30, gold["trans30"], _extent(ref))
+
+
+def test_correspondences_bit_exact_every_iteration(ctx, pair, po):
+    """Iteration k searches from the cloud after k updates.  Feeding the oracle's
+    state of each iteration keeps the inputs identical, so indices must match bit
+    for bit wherever a neighbour lies within the threshold."""
+    ref, src, gold = pair
+    ctx.set_target(ref, gold["normals"])
+    tree = po.KDTree(ref)
+    state = src.copy()
+    for k in range(5):
+        if k > 0:
+            state = refmath.apply_update(state, refmath.euler_to_RT(gold["X5"][k - 1]))
+        ctx.set_source(state)
+        T, info = ctx.run(1)
+        X, _ = ctx.history()
+        assert np.abs(X[0] - gold["X5"][k]).max() < X_TOL
+        idx, d2 = ctx.correspondences()
+        oi, od = tree.knn(state, 1)
+        hit = od[:, 0] <= 5.0
+        assert np.array_equal(idx[hit], oi[hit, 0]) and np.array_equal(d2[hit], od[hit, 0])
+        assert (idx[~hit] == -1).all() and np.isinf(d2[~hit]).all()
+        if k < 4:
+            assert np.array_equal(oi[:, 0], gold["idx5"][k])
+        assert np.array_equal(ctx.get_source(), state)       # one solve: no update applied
+
+
+def test_compat_class_updates_caller_buffer(pair, capsys):
+    import stereovision_amd as sv
+    ref, src, gold = pair
+    icp = sv.CPoint2PlaneICP()
+    icp.setReferenceData(ref)
+    move = src.copy()
+    icp.setMoveData(move)
+    icp.setMaxIterateCount(5)
+    icp.run()
+    assert "Current Transformation:" in capsys.readouterr().out
+    _check_transform(icp.getTransform(), gold["trans5"], _extent(ref))
+    assert np.abs(move - gold["src5"]).max() <= 4e-5 and not np.array_equal(move, src)
+    # a second run continues from the updated cloud, as the reference would
+    icp.setMaxIterateCount(1)
+    icp.run()
+    assert np.abs(icp.getTransform()[:3, 3]).max() < 1e-3
+
+
+def test_knn_class(pair, po):
+    import stereovision_amd as sv
+    ref, src, gold = pair
+    knn = sv.CKNNSearch()
+    knn.setTreeData(ref)
+    knn.setQueryData(src[:500])
+    knn.setKCount(200)                       # clamps to 128 (CKNNSearch.cpp:60-65)
+    idx, d2 = knn.getKNeighbour()
+    assert idx.shape == (500, 128)
+    oi, od = po.KDTree(ref).knn(src[:500], 128)
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+
+
+# ---------------------------------------------------------------- synthetic
+@pytest.mark.parametrize("side", [32, 100, 256])
+def test_synthetic_pair_matches_oracle(ctx, po, side):
+    from stereovision_amd import synth
+    tgt, nrm, src, P = synth.make_pair(side)
+    ctx.set_target(tgt, nrm)
+    ctx.set_source(src)
+    T, info = ctx.run(6)
+    X, I = ctx.history()
+    r = po.icp_point2plane(po.KDTree(tgt), nrm, src, 6)
+    _check_transform(T, r["trans"], _extent(tgt))
+    assert np.abs(X - r["X"]).max() < X_TOL
+    assert np.array_equal(I[:, 0], r["info"][:, 0])
+    idx, d2 = ctx.correspondences()
+    # states can differ by an fp32 ulp after several fp64-summed solves; indices still agree
+    hit = r["d2"][-1] <= 4.99
+    assert (idx[hit] == r["idx"][-1][hit]).mean() > 0.9999
+
+
+def test_unsorted_source_gives_same_sums(ctx, po, synth32):
+    tgt, nrm, src = synth32["target"], synth32["normals"], synth32["source"]
+    ctx.set_target(tgt, nrm)
+    ctx.set_source(src)
+    T1, _ = ctx.run(3)
+    ctx.set_options(sort_source=0)
+    ctx.set_source(src)
+    T2, _ = ctx.run(3)
+    assert np.abs(T1 - T2).max() < 1e-10
+    perm = np.random.default_rng(0).permutation(len(src))
+    ctx.set_source(np.ascontiguousarray(src[perm]))
+    T3, _ = ctx.run(3)
+    assert np.abs(T1 - T3).max() < 1e-10
+    out = ctx.get_source()
+    ctx.set_options(sort_source=1)
+    ctx.set_source(src)
+    ctx.run(3)
+    assert np.abs(out - ctx.get_source()[perm]).max() <= 4e-5
+
+
+# ---------------------------------------------------------------- edge cases
+def test_ties_resolve_to_lowest_index(ctx, lattice):
+    ctx.set_target(lattice["target"], np.zeros_like(lattice["target"]))
+    idx, d2 = ctx.knn(lattice["query"], 8)
+    assert np.array_equal(idx, lattice["idx"]) and np.array_equal(d2, lattice["d2"])
+    i1, _ = ctx.knn(lattice["query"], 1)
+    assert np.array_equal(i1[:, 0], lattice["idx"][:, 0])
+
+
+def test_duplicates_and_k_larger_than_target(ctx):
+    tgt = np.float32([[0, 0, 0], [1, 0, 0], [0, 0, 0], [0, 2, 0]])
+    ctx.set_target(tgt, np.zeros_like(tgt))
+    idx, d2 = ctx.knn(np.float32([[0.1, 0, 0]]), 6)
+    assert list(idx[0]) == [0, 2, 1, 3, -1, -1]
+    assert np.isinf(d2[0, 4:]).all() and d2[0, 0] == d2[0, 1]
+
+
+def test_far_queries_use_the_exhaustive_pass(ctx, po, synth32):
+    tgt = synth32["target"]
+    ctx.set_target(tgt, synth32["normals"])
+    rng = np.random.default_rng(5)
+    q = (tgt[rng.integers(0, len(tgt), 64)] + rng.normal(size=(64, 3)) * 300).astype(np.float32)
+    q[0] = [1e6, -1e6, 1e6]
+    tree = po.KDTree(tgt)
+    for k in (1, 5):
+        gi, gd = ctx.knn(q, k)
+        oi, od = tree.knn(q, k)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+def test_no_overlap_is_reported_singular(ctx, synth32):
+    import stereovision_amd as sv
+    ctx.set_target(synth32["target"], synth32["normals"])
+    ctx.set_source(synth32["source"] + np.float32(1000.0))
+    with pytest.raises(sv.SvicpError) as e:
+        ctx.run(2)
+    assert e.value.status == sv._lib.ERR_SINGULAR
+    idx, d2 = ctx.correspondences()
+    assert (idx == -1).all()
+
+
+def test_empty_and_tiny_inputs(ctx, synth32):
+    import stereovision_amd as sv
+    tgt, nrm = synth32["target"], synth32["normals"]
+    ctx.set_target(tgt, nrm)
+    ctx.set_source(np.zeros((0, 3), np.float32))
+    with pytest.raises(sv.SvicpError):
+        ctx.run(1)
+    assert ctx.get_source().shape == (0, 3)
+    idx, d2 = ctx.knn(np.zeros((0, 3), np.float32), 3)
+    assert idx.shape == (0, 3)
+    ctx.set_source(tgt[:1].copy())
+    with pytest.raises(sv.SvicpError):        # one row cannot fix six unknowns
+        ctx.run(1)
+    ctx.set_target(np.zeros((0, 3), np.float32))
+    idx, d2 = ctx.knn(tgt[:4], 2)
+    assert (idx == -1).all() and np.isinf(d2).all()
+    with pytest.raises(sv.SvicpError):
+        ctx.run(0)
+
+
+def test_call_order_is_checked():
+    import stereovision_amd as sv
+    c = sv.Context(0)
+    with pytest.raises(sv.SvicpError) as e:
+        c.run(1)
+    assert e.value.status == sv._lib.ERR_ARG
+    with pytest.raises(sv.SvicpError):
+        c.knn(np.zeros((1, 3), np.float32), 1)
+    c.close()
+
+
+# ---------------------------------------------------------------- full size
+def test_one_million_points_properties(ctx):
+    """The benchmark's configuration: 1024^2 points, 30 iterations.  The oracle
+    needs ~1 s per iteration here, so this checks size-independent properties:
+    the recovered motion undoes the generating pose, returned distances are the
+    distances to the returned indices, no sampled point is closer, and a
+    shuffled source gives the same answer."""
+    from stereovision_amd import synth
+    tgt, nrm, src, P = synth.make_pair(1024)
+    ctx.set_target(tgt, nrm)
+    ctx.set_source(src)
+    T, info = ctx.run(30)
+    Pinv = np.linalg.inv(P)
+    assert refmath.rot_angle(T[:3, :3], Pinv[:3, :3]) < 2e-5
+    moved = src.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    truth = src.astype(np.float64) @ Pinv[:3, :3].T + Pinv[:3, 3]
+    assert np.sqrt(((moved - truth) ** 2).sum(1)).max() < 0.05
+    assert info.inliers > 0.98 * len(src) and info.step_norm < 1e-4
+
+    idx, d2 = ctx.correspondences()
+    cur = ctx.get_source()
+    hit = idx >= 0
+    assert hit.mean() > 0.98 and (d2[hit] <= 5.0).all()
+    diff = cur[hit] - tgt[idx[hit]]
+    re = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]).astype(np.float32)
+    re = (re + diff[:, 2] * diff[:, 2]).astype(np.float32)
+    assert np.array_equal(re, d2[hit])
+    rng = np.random.default_rng(3)
+    rows = rng.integers(0, len(cur), 2000)
+    cand = rng.integers(0, len(tgt), 4000)
+    dd = ((cur[rows, None, :].astype(np.float64) - tgt[None, cand, :]) ** 2).sum(-1).min(1)
+    ok = np.where(idx[rows] >= 0, d2[rows] <= dd * (1 + 1e-6), dd > 5.0 * (1 - 1e-6))
+    assert ok.all()
+
+    perm = rng.permutation(len(src))
+    ctx.set_source(np.ascontiguousarray(src[perm]))
+    T2, _ = ctx.run(30)
+    assert refmath.rot_angle(T[:3, :3], T2[:3, :3]) < 1e-9
+    assert np.abs(T[:3, 3] - T2[:3, 3]).max() < 1e-6
+
+
+def test_exact_and_capped_search_agree_within_threshold(ctx, po):
+    from stereovision_amd import synth
+    tgt, nrm, src, _ = synth.make_pair(128)
+    ctx.set_target(tgt, nrm)
+    ctx.set_source(src)
+    capped_i, capped_d = ctx.correspondences()
+    exact_i, exact_d = ctx.knn(src, 1)
+    oi, od = po.KDTree(tgt).knn(src, 1)
+    assert np.array_equal(exact_i, oi) and np.array_equal(exact_d, od)
+    hit = od[:, 0] <= 5.0
+    assert np.array_equal(capped_i[hit], oi[hit, 0]) and (capped_i[~hit] == -1).all()
+    assert ctx.time_nn(exact=True, reps=2) > 0 and ctx.time_nn(exact=False, reps=2) > 0
