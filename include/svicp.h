@@ -46,7 +46,10 @@ typedef struct svicp_options {
                               svicp_kernel_times reports per-kernel durations         */
     int sort_source;       /* 1: keep the source in Morton order on the device (the
                               caller-visible order is unchanged)                      */
-    int blocks_per_cu;     /* launch width of the per-iteration kernel, default 4     */
+    int coherent;          /* 1: from the second iteration on, a point whose previous
+                              correspondence is provably still its nearest neighbour
+                              skips the search (same result, bit for bit); 0: search
+                              every point in every iteration                          */
 } svicp_options;
 
 /* Per-run summary.  Arrays hold the LAST iteration's figures. */
@@ -171,6 +174,10 @@ int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info);
  * options.time_kernels = 1, of the per-iteration correspondence+accumulate
  * kernel and of the solve kernel, and the number of launches averaged. */
 int svicp_kernel_times(svicp_ctx *ctx, double *fused_ms, double *solve_ms, int *launches);
+
+/* Per-iteration durations (milliseconds) of the same two kernels over the last
+ * timed svicp_run: `iterations` entries each.  Either pointer may be NULL. */
+int svicp_iteration_times(svicp_ctx *ctx, double *fused_ms_out, double *solve_ms_out);
 
 /* Runs the standalone 1-NN kernel `reps` times over the resident source and
  * reports its average duration.  exact = 0: radius-capped search as the ICP

@@ -25,7 +25,7 @@ class Options(C.Structure):
         ("use_graph", C.c_int),
         ("time_kernels", C.c_int),
         ("sort_source", C.c_int),
-        ("blocks_per_cu", C.c_int),
+        ("coherent", C.c_int),
     ]
 
 
@@ -67,6 +67,7 @@ SYMBOLS = {
     "svicp_shard_update": (C.c_int, [_ctx, C.c_void_p]),
     "svicp_shard_finish": (C.c_int, [_ctx, _dp, C.POINTER(Info)]),
     "svicp_kernel_times": (C.c_int, [_ctx, _dp, _dp, C.POINTER(C.c_int)]),
+    "svicp_iteration_times": (C.c_int, [_ctx, _dp, _dp]),
     "svicp_time_nn": (C.c_int, [_ctx, C.c_int, C.c_int, _dp]),
     "svicp_sizes": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -58,13 +59,14 @@ struct svicp_ctx {
     bool have_source = false, sorted = false;
     int cur = 0;   // 0: the pristine copy is current, 1: the work copy
     DevBuf sx0, sy0, sz0, wx, wy, wz, perm;
+    DevBuf st_tp, st_nv, st_lb;   // per source point: matched target point, normal, bound
 
     // scratch shared by the set-up steps
     DevBuf tmp_aos, keys_a, keys_b, vals_a, vals_b, marks, ranks, block_of_rank, sort_tmp, bbox6;
     DevBuf knn_idx, knn_d2, unresolved, n_unres;
 
     // iteration loop
-    DevBuf partials, state, xhist, ihist;
+    DevBuf partials, sums, state, xhist, ihist;
     IcpState *h_state = nullptr;   // pinned
     int hist_cap = 0, last_iters = 0;
     int nb = 0, chunk = 0;
@@ -74,9 +76,11 @@ struct svicp_ctx {
     // timing
     std::vector<hipEvent_t> events;
     double fused_ms = 0, solve_ms = 0;
+    std::vector<double> fused_it, solve_it;
     int timed_launches = 0;
 
     int shard_iter = 0;
+    int variant = 4;   // candidates loaded per chunk in the 1-NN walk
 };
 
 namespace {
@@ -191,14 +195,14 @@ int run_nn1(svicp_ctx *ctx, bool exact)
     const int *perm = ctx->sorted ? ctx->perm.as<int>() : nullptr;
     const int grid = std::min(cdiv(n, kBlockThreads), ctx->num_cus * 8);
     if (!exact) {
-        hipLaunchKernelGGL((nn1_kernel<false>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
+        hipLaunchKernelGGL((nn1_kernel<false, 4>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
                            ctx->g, x, y, z, perm, (int)n, ctx->opt.dist_threshold,
                            ctx->knn_idx.as<int>(), ctx->knn_d2.as<float>(), (int *)nullptr,
                            (int *)nullptr);
         LAUNCHCHK("nn1_kernel");
     } else {
         HIPCHK(hipMemsetAsync(ctx->n_unres.p, 0, sizeof(int), ctx->stream));
-        hipLaunchKernelGGL((nn1_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
+        hipLaunchKernelGGL((nn1_kernel<true, 4>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
                            ctx->g, x, y, z, perm, (int)n, ctx->opt.dist_threshold,
                            ctx->knn_idx.as<int>(), ctx->knn_d2.as<float>(),
                            ctx->unresolved.as<int>(), ctx->n_unres.as<int>());
@@ -215,14 +219,21 @@ int run_nn1(svicp_ctx *ctx, bool exact)
 int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
 {
     const int64_t n = ctx->n;
-    int bpc = ctx->opt.blocks_per_cu > 0 ? ctx->opt.blocks_per_cu : 4;
-    int nb = std::max(1, std::min(cdiv(std::max<int64_t>(n, 1), kBlockThreads), ctx->num_cus * bpc));
-    int chunk = cdiv(cdiv(std::max<int64_t>(n, 1), nb), kBlockThreads) * kBlockThreads;
-    nb = std::max(1, cdiv(std::max<int64_t>(n, 1), chunk));
+    const int chunk = kItTile;
+    const int nb = std::max(1, cdiv(std::max<int64_t>(n, 1), chunk));
     if (nb != ctx->nb || chunk != ctx->chunk) drop_graph(ctx);
     ctx->nb = nb; ctx->chunk = chunk;
+    {
+        DevBuf *bufs[] = { &ctx->st_tp, &ctx->st_nv };
+        for (DevBuf *b : bufs) {
+            void *before = b->p;
+            HIPCHK(b->reserve(sizeof(float4) * (size_t)std::max<int64_t>(n, 1)));
+            if (b->p != before) drop_graph(ctx);
+        }
+    }
     HIPCHK(ctx->partials.reserve(sizeof(double) * kNumSums * nb));
     HIPCHK(ctx->state.reserve(sizeof(IcpState)));
+    HIPCHK(ctx->sums.reserve(sizeof(double) * kNumSums));
     if (iters > ctx->hist_cap) {
         drop_graph(ctx);
         int cap = std::max(iters, 64);
@@ -234,22 +245,40 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
     return SVICP_OK;
 }
 
-// launches one iteration's accumulate kernel; k = iteration number
-void launch_accumulate(svicp_ctx *ctx, int k, double *partials)
+// launches iteration k's kernel; the tile sums end up in `partials`
+void launch_iteration(svicp_ctx *ctx, int k, double *partials)
 {
-    const float *ix = (k <= 1) ? ctx->sx0.as<float>() : ctx->wx.as<float>();
-    const float *iy = (k <= 1) ? ctx->sy0.as<float>() : ctx->wy.as<float>();
-    const float *iz = (k <= 1) ? ctx->sz0.as<float>() : ctx->wz.as<float>();
-    if (k == 0)
-        hipLaunchKernelGGL((icp_accumulate_kernel<false>), dim3(ctx->nb), dim3(kBlockThreads), 0,
-                           ctx->stream, ctx->g, ix, iy, iz, (float *)nullptr, (float *)nullptr,
-                           (float *)nullptr, (int)ctx->n, ctx->chunk,
-                           ctx->state.as<IcpState>(), ctx->opt.dist_threshold, partials);
+    const float thr = ctx->opt.dist_threshold;
+    CohParams cp;
+    cp.thr = thr;
+    cp.root_hi = std::sqrt(thr) * 1.00001f;
+    cp.cov = std::sqrt(thr) * 1.001f;   // inside the probe radius rr = sqrt(thr) * 1.002 + slack
+    PointState ps;
+    ps.tp = ctx->st_tp.as<float4>();
+    ps.nv = ctx->st_nv.as<float4>();
+    ps.lb = ctx->st_lb.as<float>();
+    float *wx = ctx->wx.as<float>(), *wy = ctx->wy.as<float>(), *wz = ctx->wz.as<float>();
+    const float *x0 = ctx->sx0.as<float>(), *y0 = ctx->sy0.as<float>(), *z0 = ctx->sz0.as<float>();
+    IcpState *state = ctx->state.as<IcpState>();
+    const double *sums = ctx->sums.as<double>();
+    double *xh = ctx->xhist.as<double>(), *ih = ctx->ihist.as<double>();
+    const dim3 grid(ctx->nb), block(kItThreads);
+    const int n = (int)ctx->n;
+    if (k == 0) {
+        hipLaunchKernelGGL((icp_iterate_kernel<false, false, 4>), grid, block, 0, ctx->stream,
+                           ctx->g, x0, y0, z0, wx, wy, wz, n, sums, state, xh, ih, k, cp, ps,
+                           partials);
+        return;
+    }
+    const float *ix = k == 1 ? x0 : wx, *iy = k == 1 ? y0 : wy, *iz = k == 1 ? z0 : wz;
+    if (ctx->opt.coherent)
+        hipLaunchKernelGGL((icp_iterate_kernel<true, true, 4>), grid, block, 0, ctx->stream,
+                           ctx->g, ix, iy, iz, wx, wy, wz, n, sums, state, xh, ih, k, cp, ps,
+                           partials);
     else
-        hipLaunchKernelGGL((icp_accumulate_kernel<true>), dim3(ctx->nb), dim3(kBlockThreads), 0,
-                           ctx->stream, ctx->g, ix, iy, iz, ctx->wx.as<float>(),
-                           ctx->wy.as<float>(), ctx->wz.as<float>(), (int)ctx->n, ctx->chunk,
-                           ctx->state.as<IcpState>(), ctx->opt.dist_threshold, partials);
+        hipLaunchKernelGGL((icp_iterate_kernel<true, false, 4>), grid, block, 0, ctx->stream,
+                           ctx->g, ix, iy, iz, wx, wy, wz, n, sums, state, xh, ih, k, cp, ps,
+                           partials);
 }
 
 int enqueue_loop(svicp_ctx *ctx, int iters, bool timed)
@@ -259,16 +288,21 @@ int enqueue_loop(svicp_ctx *ctx, int iters, bool timed)
     LAUNCHCHK("reset_state_kernel");
     for (int k = 0; k < iters; ++k) {
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 0], ctx->stream));
-        launch_accumulate(ctx, k, ctx->partials.as<double>());
-        LAUNCHCHK("icp_accumulate_kernel");
+        launch_iteration(ctx, k, ctx->partials.as<double>());
+        LAUNCHCHK("icp_iterate_kernel");
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 1], ctx->stream));
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 2], ctx->stream));
-        hipLaunchKernelGGL(reduce_solve_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                           ctx->partials.as<double>(), ctx->nb, ctx->state.as<IcpState>(),
-                           ctx->xhist.as<double>(), ctx->ihist.as<double>(), k, (double *)nullptr);
-        LAUNCHCHK("reduce_solve_kernel");
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(30), dim3(256), 0, ctx->stream,
+                           ctx->partials.as<double>(), ctx->nb, ctx->sums.as<double>());
+        LAUNCHCHK("reduce_rows_kernel");
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 3], ctx->stream));
     }
+    // the last iteration's system is solved here; the others were solved at the
+    // start of the following iteration's kernel
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->sums.as<double>(),
+                       ctx->state.as<IcpState>(), ctx->xhist.as<double>(),
+                       ctx->ihist.as<double>(), iters - 1);
+    LAUNCHCHK("solve_kernel");
     return SVICP_OK;
 }
 
@@ -301,7 +335,7 @@ int svicp_default_options(svicp_options *opt)
     opt->use_graph = 1;
     opt->time_kernels = 0;
     opt->sort_source = 1;
-    opt->blocks_per_cu = 4;
+    opt->coherent = 1;
     return SVICP_OK;
 }
 
@@ -330,6 +364,7 @@ int svicp_create(int device_id, svicp_ctx **out)
     ctx->device = device_id;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     svicp_default_options(&ctx->opt);
+    if (const char *v = std::getenv("SVICP_VARIANT")) ctx->variant = std::atoi(v);
     e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, SVICP_ERR_HIP, "hipStreamCreate", e); }
     ctx->stream = ctx->own_stream;
@@ -346,10 +381,10 @@ int svicp_destroy(svicp_ctx *ctx)
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     DevBuf *bufs[] = { &ctx->tgt_aos, &ctx->nrm_aos, &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->run2,
                        &ctx->end1, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx, &ctx->wy, &ctx->wz,
-                       &ctx->perm, &ctx->tmp_aos, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
+                       &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->perm, &ctx->tmp_aos, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
                        &ctx->vals_b, &ctx->marks, &ctx->ranks, &ctx->block_of_rank,
                        &ctx->sort_tmp, &ctx->bbox6, &ctx->knn_idx, &ctx->knn_d2,
-                       &ctx->unresolved, &ctx->n_unres, &ctx->partials, &ctx->state, &ctx->xhist,
+                       &ctx->unresolved, &ctx->n_unres, &ctx->partials, &ctx->sums, &ctx->state, &ctx->xhist,
                        &ctx->ihist };
     for (DevBuf *b : bufs) b->release();
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -585,7 +620,8 @@ int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n)
     if (n != ctx->n) drop_graph(ctx);
     ctx->have_source = false;
     const int64_t nn = std::max<int64_t>(n, 1);
-    DevBuf *soa[] = { &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx, &ctx->wy, &ctx->wz };
+    DevBuf *soa[] = { &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx, &ctx->wy, &ctx->wz,
+                      &ctx->st_lb };
     for (DevBuf *b : soa) {
         void *before = b->p;
         HIPCHK(b->reserve(sizeof(float) * nn));
@@ -703,12 +739,16 @@ int svicp_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info
 
     if (timed) {
         double fa = 0, so = 0;
+        ctx->fused_it.assign(iterations, 0.0);
+        ctx->solve_it.assign(iterations, 0.0);
         for (int k = 0; k < iterations; ++k) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ctx->events[4 * k + 0], ctx->events[4 * k + 1]));
             fa += ms;
+            ctx->fused_it[k] = ms;
             HIPCHK(hipEventElapsedTime(&ms, ctx->events[4 * k + 2], ctx->events[4 * k + 3]));
             so += ms;
+            ctx->solve_it[k] = ms;
         }
         ctx->fused_ms = fa / iterations;
         ctx->solve_ms = so / iterations;
@@ -801,12 +841,12 @@ int svicp_shard_accumulate(svicp_ctx *ctx, double *dev_partial32)
     HIPCHK(hipSetDevice(ctx->device));
     int rc = ensure_iteration_buffers(ctx, ctx->shard_iter + 1);
     if (rc) return rc;
-    launch_accumulate(ctx, ctx->shard_iter, ctx->partials.as<double>());
-    LAUNCHCHK("icp_accumulate_kernel");
-    hipLaunchKernelGGL(reduce_solve_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                       ctx->partials.as<double>(), ctx->nb, ctx->state.as<IcpState>(),
-                       (double *)nullptr, (double *)nullptr, ctx->shard_iter, dev_partial32);
-    LAUNCHCHK("reduce_solve_kernel(partial)");
+    launch_iteration(ctx, ctx->shard_iter, ctx->partials.as<double>());
+    LAUNCHCHK("icp_iterate_kernel");
+    HIPCHK(hipMemsetAsync(dev_partial32, 0, sizeof(double) * kNumSums, ctx->stream));
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(30), dim3(256), 0, ctx->stream,
+                       ctx->partials.as<double>(), ctx->nb, dev_partial32);
+    LAUNCHCHK("reduce_rows_kernel");
     if (ctx->shard_iter >= 1) ctx->cur = 1;
     return SVICP_OK;
 }
@@ -815,10 +855,9 @@ int svicp_shard_update(svicp_ctx *ctx, const double *dev_sum32)
 {
     if (!ctx || !dev_sum32) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_update: NULL argument");
     HIPCHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(solve_from_sums_kernel, dim3(1), dim3(64), 0, ctx->stream, dev_sum32,
-                       ctx->state.as<IcpState>(), ctx->xhist.as<double>(), ctx->ihist.as<double>(),
-                       ctx->shard_iter);
-    LAUNCHCHK("solve_from_sums_kernel");
+    // the sum is consumed by the next svicp_shard_accumulate (or _finish)
+    HIPCHK(hipMemcpyAsync(ctx->sums.p, dev_sum32, sizeof(double) * kNumSums,
+                          hipMemcpyDeviceToDevice, ctx->stream));
     ctx->shard_iter++;
     ctx->last_iters = ctx->shard_iter;
     return SVICP_OK;
@@ -828,6 +867,11 @@ int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info)
 {
     if (!ctx || !T_out) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_finish: NULL argument");
     HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->shard_iter < 1) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_finish: no iteration was run");
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->sums.as<double>(),
+                       ctx->state.as<IcpState>(), ctx->xhist.as<double>(),
+                       ctx->ihist.as<double>(), ctx->shard_iter - 1);
+    LAUNCHCHK("solve_kernel");
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->state.p, sizeof(IcpState), hipMemcpyDeviceToHost,
                           ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -844,6 +888,14 @@ int svicp_kernel_times(svicp_ctx *ctx, double *fused_ms, double *solve_ms, int *
     if (fused_ms) *fused_ms = ctx->fused_ms;
     if (solve_ms) *solve_ms = ctx->solve_ms;
     if (launches) *launches = ctx->timed_launches;
+    return SVICP_OK;
+}
+
+int svicp_iteration_times(svicp_ctx *ctx, double *fused_ms_out, double *solve_ms_out)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (fused_ms_out) std::copy(ctx->fused_it.begin(), ctx->fused_it.end(), fused_ms_out);
+    if (solve_ms_out) std::copy(ctx->solve_it.begin(), ctx->solve_it.end(), solve_ms_out);
     return SVICP_OK;
 }
 

@@ -48,6 +48,8 @@ struct IcpState {
     int pad;
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ bool better(float d, int id, float bd, int bid)
 {
     return (d < bd) || (d == bd && id < bid);
@@ -91,10 +93,17 @@ __device__ __forceinline__ bool probe_origin(const GridDesc &g, float qx, float 
 
 // Nearest target point within the probe radius: the 1-NN the ICP loop needs.
 // best = +inf, bpos = -1 when the probed cells are empty.
+//
+// The four runs are walked as one flat candidate list, CH candidates at a
+// time: the CH loads of a chunk are issued together (one memory latency per
+// chunk instead of one per candidate) and a wave iterates max-over-lanes of
+// the TOTAL candidate count, not the sum of per-run maxima.
+template <int CH, bool SECOND = false>
 __device__ __forceinline__ void nn_capped(const GridDesc &g, float qx, float qy, float qz,
-                                          float &best, int &bpos, int &bidx)
+                                          float &best, int &bpos, int &bidx, float *second = nullptr)
 {
     best = INFINITY; bpos = -1; bidx = 0x7fffffff;
+    if (SECOND) *second = INFINITY;
     int cx, cy, cz;
     if (!probe_origin(g, qx, qy, qz, cx, cy, cz)) return;
 
@@ -105,19 +114,65 @@ __device__ __forceinline__ void nn_capped(const GridDesc &g, float qx, float qy,
     uint2 run[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        run[r] = make_uint2(0u, 0u);
-        if (rank[r] >= 0)
-            run[r] = g.run2[rank[r] * 64 + cell_local(cx, cy + (r & 1), cz + (r >> 1))];
+        // an unranked block has no entry: read entry 0 of the table and drop it
+        int e = rank[r] >= 0 ? rank[r] * 64 + cell_local(cx, cy + (r & 1), cz + (r >> 1)) : 0;
+        uint2 v = g.run2[e];
+        run[r] = rank[r] >= 0 ? v : make_uint2(0u, 0u);
     }
+    constexpr int C = CH;
+    static_assert(C >= 2 && C % 2 == 0, "candidates are evaluated in pairs");
+    const unsigned P1 = run[0].y - run[0].x;
+    const unsigned P2 = P1 + (run[1].y - run[1].x);
+    const unsigned P3 = P2 + (run[2].y - run[2].x);
+    const unsigned T = P3 + (run[3].y - run[3].x);
+    const unsigned o0 = run[0].x, o1 = run[1].x - P1, o2 = run[2].x - P2, o3 = run[3].x - P3;
+    // (distance bits, index) as one 64-bit key: distances are >= +0, so their
+    // bit patterns order like the values and one unsigned compare applies the
+    // rule "smaller distance, then smaller index".  A slot past the end gets
+    // distance +inf, which never beats the initial key.
+    unsigned long long bkey = (unsigned long long)0x7f800000u << 32;
+    float b1 = INFINITY, b2 = INFINITY;   // two smallest distances (SECOND only)
+    const v2f q2x = { qx, qx }, q2y = { qy, qy }, q2z = { qz, qz };
+    for (unsigned f = 0; f < T; f += C) {
+        float4 p[C];
+        unsigned jj[C];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        for (unsigned j = run[r].x; j < run[r].y; ++j) {
-            float4 p = g.pts[j];
-            float d = dist2(qx, qy, qz, p);
-            int id = __float_as_int(p.w);
-            if (better(d, id, best, bidx)) { best = d; bpos = (int)j; bidx = id; }
+        for (int c = 0; c < C; ++c) {
+            unsigned ff = f + c;
+            unsigned j = ff + (ff < P1 ? o0 : ff < P2 ? o1 : ff < P3 ? o2 : o3);
+            jj[c] = ff < T ? j : 0u;     // past the end: re-read point 0, result dropped
+            p[c] = g.pts[jj[c]];
+        }
+#pragma unroll
+        for (int c = 0; c < C; c += 2) {
+            // two candidates per packed fp32 instruction; each element is the
+            // same separately rounded ((dx*dx)+dy*dy)+dz*dz as dist2()
+            v2f dx = q2x - (v2f){ p[c].x, p[c + 1].x };
+            v2f dy = q2y - (v2f){ p[c].y, p[c + 1].y };
+            v2f dz = q2z - (v2f){ p[c].z, p[c + 1].z };
+            v2f d = dx * dx;
+            d = d + dy * dy;
+            d = d + dz * dz;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float de = (f + c + e < T) ? (e ? d.y : d.x) : INFINITY;
+                unsigned long long key = ((unsigned long long)__float_as_uint(de) << 32) |
+                                         __float_as_uint(p[c + e].w);
+                bool take = key < bkey;
+                bkey = take ? key : bkey;
+                bpos = take ? (int)jj[c + e] : bpos;
+                if (SECOND) {
+                    b2 = fminf(b2, fmaxf(de, b1));
+                    b1 = fminf(b1, de);
+                }
+            }
         }
     }
+    if (bpos >= 0) {
+        best = __uint_as_float((unsigned)(bkey >> 32));
+        bidx = (int)(unsigned)bkey;
+    }
+    if (SECOND) *second = b2;
 }
 
 // Visits every target point in the cell box [x0,x1] x [y0,y1] x [z0,z1]
@@ -181,6 +236,29 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Sum over the 64 lanes by data-parallel-primitive moves (no LDS traffic):
+// four shifts inside each row of 16 lanes, then the row totals are passed on
+// to the next rows.  The total is valid in lane 63 only.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi2, lo2);
+}
+
+__device__ __forceinline__ double wave_sum_lane63(double v)
+{
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of each row holds the row total
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // ------------------------------------------------------------------------
 // The per-iteration kernel: transform, correspondence search, residual,
 // Jacobian row and normal-equation accumulation in one pass over the source.
@@ -188,254 +266,461 @@ __device__ __forceinline__ double wave_sum(double v)
 // Restates CPoint2PlaneICP.cpp:42-50 (update, fp64 math rounded to fp32),
 // :65-79 (1-NN, weight) and :85-109 (row assembly, weighted normal equations).
 // ------------------------------------------------------------------------
-template <bool APPLY>
-__global__ __launch_bounds__(kBlockThreads) void icp_accumulate_kernel(
-    GridDesc g, const float *__restrict__ sx_in, const float *__restrict__ sy_in,
-    const float *__restrict__ sz_in, float *__restrict__ sx_out, float *__restrict__ sy_out,
-    float *__restrict__ sz_out, int n, int chunk, const IcpState *__restrict__ st, float thr,
-    double *__restrict__ partials)
+constexpr int kItThreads = 256;                  // threads per block of the iteration kernels
+constexpr int kItPoints = 2;                     // points a thread holds at once
+constexpr int kItHalves = 2;                     // passes of kItPoints per tile
+constexpr int kItTile = kItThreads * kItPoints * kItHalves;   // source points per block
+
+// Row assembly and normal-equation terms of one correspondence
+// (CPoint2PlaneICP.cpp:68-79 weight, :85-99 row, :101-109 weighted products).
+__device__ __forceinline__ void accumulate_point(double (&acc)[30], float px, float py, float pz,
+                                                 float best, float thr, float tx, float ty,
+                                                 float tz, float nx, float ny, float nz)
 {
-    // blocks that share an XCD (blockIdx % 8 equal) take neighbouring chunks,
-    // so each XCD's L2 sees one contiguous stretch of the Morton-ordered source
-    const int nb = (int)gridDim.x;
-    const int q8 = nb >> 3, r8 = nb & 7;
-    const int xcd = (int)blockIdx.x & 7, within = (int)blockIdx.x >> 3;
-    const int vb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
-
-    double R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1, T0 = 0, T1 = 0,
-           T2 = 0;
-    if (APPLY) {
-        R0 = st->R[0]; R1 = st->R[1]; R2 = st->R[2]; R3 = st->R[3]; R4 = st->R[4]; R5 = st->R[5];
-        R6 = st->R[6]; R7 = st->R[7]; R8 = st->R[8]; T0 = st->T[0]; T1 = st->T[1]; T2 = st->T[2];
+    float sl = best / thr;
+    float ss = __fmul_rn(sl, sl);
+    double om = 1.0 - (double)ss;
+    float w = (float)__dmul_rn(om, om);
+    float a0 = __fsub_rn(__fmul_rn(py, nz), __fmul_rn(pz, ny));
+    float a1 = __fsub_rn(__fmul_rn(pz, nx), __fmul_rn(px, nz));
+    float a2 = __fsub_rn(__fmul_rn(px, ny), __fmul_rn(py, nx));
+    float b = __fadd_rn(__fadd_rn(__fmul_rn(__fsub_rn(tx, px), nx),
+                                  __fmul_rn(__fsub_rn(ty, py), ny)),
+                        __fmul_rn(__fsub_rn(tz, pz), nz));
+    double a[6] = { (double)a0, (double)a1, (double)a2, (double)nx, (double)ny, (double)nz };
+    double wd = (double)w, bd = (double)b;
+    int v = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        double aw = a[r] * wd;
+#pragma unroll
+        for (int c = r; c < 6; ++c) acc[v++] += aw * a[c];
+        acc[21 + r] += aw * bd;
     }
+    if (w > 0.f) acc[27] += 1.0;
+    acc[28] += wd * bd * bd;
+    acc[29] += wd;
+}
 
-    double acc[30];
-#pragma unroll
-    for (int v = 0; v < 30; ++v) acc[v] = 0.0;
-
-    const long long begin = (long long)vb * chunk;
-    const long long end = min((long long)n, begin + chunk);
-    for (long long i = begin + threadIdx.x; i < end; i += kBlockThreads) {
-        float px = sx_in[i], py = sy_in[i], pz = sz_in[i];
-        if (APPLY) {
-            // ((R0*px + R1*py) + R2*pz) + T0 in fp64, no contraction, then one rounding to fp32
-            double dx = (double)px, dy = (double)py, dz = (double)pz;
-            float nx = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R0, dx), __dmul_rn(R1, dy)), __dmul_rn(R2, dz)), T0);
-            float ny = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R3, dx), __dmul_rn(R4, dy)), __dmul_rn(R5, dz)), T1);
-            float nz = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R6, dx), __dmul_rn(R7, dy)), __dmul_rn(R8, dz)), T2);
-            px = nx; py = ny; pz = nz;
-            sx_out[i] = px; sy_out[i] = py; sz_out[i] = pz;
-        }
-        float best; int bpos, bidx;
-        nn_capped(g, px, py, pz, best, bpos, bidx);
-        if (bpos >= 0 && best <= thr) {
-            float sl = best / thr;
-            float ss = __fmul_rn(sl, sl);
-            double om = 1.0 - (double)ss;
-            float w = (float)__dmul_rn(om, om);
-            float4 t = g.pts[bpos];
-            float nx = g.nrm[3 * (size_t)bpos], ny = g.nrm[3 * (size_t)bpos + 1],
-                  nz = g.nrm[3 * (size_t)bpos + 2];
-            float a0 = __fsub_rn(__fmul_rn(py, nz), __fmul_rn(pz, ny));
-            float a1 = __fsub_rn(__fmul_rn(pz, nx), __fmul_rn(px, nz));
-            float a2 = __fsub_rn(__fmul_rn(px, ny), __fmul_rn(py, nx));
-            float b = __fadd_rn(__fadd_rn(__fmul_rn(__fsub_rn(t.x, px), nx),
-                                          __fmul_rn(__fsub_rn(t.y, py), ny)),
-                                __fmul_rn(__fsub_rn(t.z, pz), nz));
-            double a[6] = { (double)a0, (double)a1, (double)a2, (double)nx, (double)ny, (double)nz };
-            double wd = (double)w, bd = (double)b;
-            int v = 0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                double aw = a[r] * wd;
-#pragma unroll
-                for (int c = r; c < 6; ++c) acc[v++] += aw * a[c];
-                acc[21 + r] += aw * bd;
-            }
-            if (w > 0.f) acc[27] += 1.0;
-            acc[28] += wd * bd * bd;
-            acc[29] += wd;
-        }
-    }
-
-    __shared__ double red[kBlockThreads / 64][30];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int v = 0; v < 30; ++v) {
-        double s = wave_sum(acc[v]);
-        if (lane == 0) red[wv][v] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < kNumSums) {
-        double s = 0.0;
-        if (threadIdx.x < 30) {
-#pragma unroll
-            for (int w = 0; w < kBlockThreads / 64; ++w) s += red[w][threadIdx.x];
-        }
-        partials[(size_t)threadIdx.x * nb + blockIdx.x] = s;
+// Adds two doubles held by different lanes: the swap instruction exchanges the
+// upper half of `a` with the lower half of `b` (rows of 32 lanes, or odd/even
+// rows of 16 lanes), so afterwards a + b holds, in the lanes that kept `a`,
+// the sum of two lanes' a, and in the other lanes the sum of two lanes' b.
+template <bool ROW16>
+__device__ __forceinline__ double swap_add(double a, double b)
+{
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if (ROW16) {
+        auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    } else {
+        auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
     }
 }
+
+// Block sum of the 30 per-thread accumulators; thread v < 32 returns total v.
+// Per wave: two halving steps by lane swaps (32 values -> 16 -> 8 registers,
+// each row of 16 lanes then holds 16 partial sums of one value), four shifts
+// inside the rows, and the four row ends write the totals.  The order of the
+// additions is fixed.
+__device__ __forceinline__ double block_sum_30(double (&acc)[30], double (*red)[kNumSums])
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double u[16];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) u[j] = swap_add<false>(acc[2 * j], acc[2 * j + 1]);
+    u[15] = 0.0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        double w = swap_add<true>(u[2 * m], u[2 * m + 1]);
+        w = dpp_add<0x111, 0xf>(w);   // row_shr:1
+        w = dpp_add<0x112, 0xf>(w);   // row_shr:2
+        w = dpp_add<0x114, 0xf>(w);   // row_shr:4
+        w = dpp_add<0x118, 0xf>(w);   // row_shr:8 -> lane 15 of each row holds its value's total
+        // row r of register m holds value 4m + {0, 2, 1, 3}[r]
+        const int row = lane >> 4;
+        const int value = 4 * m + ((row & 1) << 1) + (row >> 1);
+        if ((lane & 15) == 15) red[wv][value] = w;
+    }
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x < 30) {
+#pragma unroll
+        for (int w = 0; w < kItThreads / 64; ++w) s += red[w][threadIdx.x];
+    }
+    return s;
+}
+
+// Search bounds shared by the two iteration kernels.
+struct CohParams {
+    float thr;        // squared-distance threshold of the weight function
+    float root_hi;    // sqrt(thr) rounded up: "farther than this" means weight 0
+    float cov;        // every target point within cov of a query lies in its probed cells
+};
+
+// What the loop remembers about each source point between iterations
+// (arrays in source order): the matched target point and its index in the
+// sorted target (-1: no target point within cov), the matched normal, and lb,
+// a lower bound on the distance from the source point to every OTHER target
+// point.
+struct PointState {
+    float4 *tp;       // {tx, ty, tz, pos as int bits}
+    float4 *nv;       // {nx, ny, nz, unused}
+    float *lb;
+};
 
 // ------------------------------------------------------------------------
 // 6x6 solve and transform update on the device.
 // Restates CPoint2PlaneICP.cpp:109 (X), :111-119 (R = Rz*Ry*Rx, T) and
 // :36-39 / :52-55 (Trans = [R T; 0 1] * Trans).
 // ------------------------------------------------------------------------
-// Called by every thread of the block; S points to 32 sums in LDS or global.
-__device__ inline void solve_and_update(const double *S, IcpState *st, double *X_hist,
-                                        double *info_hist, int iter)
+// 1/sqrt(a) to fp64 accuracy: fp32 estimate, three Newton steps.
+__device__ __forceinline__ double fast_rsqrt(double a)
 {
-    __shared__ double shX[6];
-    __shared__ double shSC[6];
-    __shared__ int shOk;
-    if (threadIdx.x == 0) {
-        // symmetric 6x6 in registers: every index below is a compile-time constant
-        double A[6][6], b[6], d[6], L[6][6], y[6], X[6];
-        {
-            int v = 0;
+    double y = (double)rsqrtf((float)a);
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c = r; c < 6; ++c) { A[r][c] = S[v]; A[c][r] = S[v]; ++v; }
-        }
-        bool ok = true;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            b[r] = S[21 + r];
-            if (!(A[r][r] > 0.0) || !isfinite(A[r][r])) ok = false;
-        }
-        // Cholesky of the diagonally scaled matrix D A D, D = diag(A)^-1/2
-#pragma unroll
-        for (int r = 0; r < 6; ++r) d[r] = ok ? 1.0 / sqrt(A[r][r]) : 1.0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c <= r; ++c) {
-                double s = A[r][c] * d[r] * d[c];
-#pragma unroll
-                for (int k = 0; k < c; ++k) s -= L[r][k] * L[c][k];
-                if (r == c) {
-                    if (!(s > 1e-14) || !isfinite(s)) { ok = false; s = 1.0; }
-                    L[r][r] = sqrt(s);
-                } else
-                    L[r][c] = s / L[c][c];
-            }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            double s = b[r] * d[r];
-#pragma unroll
-            for (int k = 0; k < r; ++k) s -= L[r][k] * y[k];
-            y[r] = s / L[r][r];
-        }
-#pragma unroll
-        for (int r = 5; r >= 0; --r) {
-            double s = y[r];
-#pragma unroll
-            for (int k = r + 1; k < 6; ++k) s -= L[k][r] * X[k];
-            X[r] = s / L[r][r];
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            X[r] *= d[r];
-            if (!isfinite(X[r])) ok = false;
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) shX[r] = ok ? X[r] : 0.0;
-        shOk = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        double sn, cs;
-        sincos(shX[threadIdx.x], &sn, &cs);
-        shSC[2 * threadIdx.x] = sn;
-        shSC[2 * threadIdx.x + 1] = cs;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+    for (int k = 0; k < 3; ++k) y = y * (1.5 - 0.5 * a * y * y);
+    return y;
+}
 
-    if (!shOk) st->status = 4;   // SVICP_ERR_SINGULAR
+// Orders LDS writes before later LDS reads of the same wave (no s_barrier:
+// the caller is a single wave, possibly while other waves of the block run on).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Wave-parallel solve, called by ONE full wave (64 lanes).  S: the 32 sums
+// (global or LDS).  Results: R (9) and T (3) to out_rt (LDS); when `record`,
+// also the state, the accumulated transform and the history rows.
+//
+// Cholesky of the diagonally scaled matrix with the right-hand side carried as
+// a seventh row, so the forward substitution falls out of the factorisation:
+// lane r owns row r; every lane recomputes the pivot of the current column.
+// Restates CPoint2PlaneICP.cpp:109 (X), :111-119 (R = Rz*Ry*Rx, T) and
+// :36-39 / :52-55 (Trans = [R T; 0 1] * Trans).
+__device__ inline void solve_and_update(const double *S, IcpState *st, double *X_hist,
+                                        double *info_hist, int iter, bool record, double *out_rt)
+{
+    __shared__ double M[7][8];     // rows 0-5: scaled matrix / factor, row 6: scaled rhs / y
+    __shared__ double shS[kNumSums];
+    __shared__ double shD[8];      // scaling d = diag^-1/2
+    __shared__ double shSC[8];
+    const int t = threadIdx.x & 63;
+    bool ok = true;
+
+    if (t < kNumSums) shS[t] = t < 30 ? S[t] : 0.0;
+    wave_lds_sync();
+    // upper triangle: element (r, c), r <= c, sits at r*6 - r(r-1)/2 + (c - r)
+    if (t < 6) {
+        const double a = shS[t * 6 - (t * (t - 1)) / 2];
+        shD[t] = (a > 1e-300 && a < 1e300) ? fast_rsqrt(a) : 0.0;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ok = ok && (shD[k] > 0.0);
+    if (t < 49) {
+        const int r = t / 7, c = t % 7;
+        if (r < 6 && c < 6) {
+            const int lo = r < c ? r : c, hi = r < c ? c : r;
+            M[r][c] = shS[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)] * shD[r] * shD[c];
+        } else if (r == 6 && c < 6) {
+            M[6][c] = shS[21 + c] * shD[c];
+        }
+    }
+    wave_lds_sync();
+
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        double piv = M[c][c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) piv -= M[c][k] * M[c][k];
+        if (!(piv > 1e-14) || !(piv < 1e300)) { ok = false; piv = 1.0; }
+        const double inv = fast_rsqrt(piv);
+        double mine = 0.0;
+        if (t > c && t < 7) {
+            mine = M[t][c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) mine -= M[t][k] * M[c][k];
+            mine *= inv;
+        }
+        wave_lds_sync();
+        if (t > c && t < 7) M[t][c] = mine;
+        if (t == c) { M[c][c] = piv * inv; M[c][7] = inv; }   // L_cc and its reciprocal
+        wave_lds_sync();
+    }
+    // back substitution L^T x = y, every lane redundantly
+    double x[6];
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {
+        double v = M[6][r];
+#pragma unroll
+        for (int k = r + 1; k < 6; ++k) v -= M[k][r] * x[k];
+        x[r] = v * M[r][7];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        x[r] *= shD[r];
+        if (!(fabs(x[r]) < 1e300)) ok = false;
+    }
+    if (!ok) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) x[r] = 0.0;
+    }
+    if (t < 3) {
+        double sn, cs;
+        sincos(t == 0 ? x[0] : t == 1 ? x[1] : x[2], &sn, &cs);
+        shSC[2 * t] = sn;
+        shSC[2 * t + 1] = cs;
+    }
+    wave_lds_sync();
     const double sx = shSC[0], cx = shSC[1], sy = shSC[2], cy = shSC[3], sz = shSC[4], cz = shSC[5];
-    const double X0 = shX[0], X1 = shX[1], X2 = shX[2], X3 = shX[3], X4 = shX[4], X5 = shX[5];
     // R = Rz(X2) * Ry(X1) * Rx(X0)
     const double R[9] = { cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
                           sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx,
                           -sy,     cy * sx,                cy * cx };
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out_rt[k] = R[k];
+        out_rt[9] = x[3]; out_rt[10] = x[4]; out_rt[11] = x[5];
+    }
+    if (!record) return;
+
+    // Trans = [R T; 0 1] * Trans, one element per lane
+    double tnew = 0.0;
+    if (t < 12) {
+        const int r = t >> 2, c = t & 3;
+        const double r0 = r == 0 ? R[0] : r == 1 ? R[3] : R[6];
+        const double r1 = r == 0 ? R[1] : r == 1 ? R[4] : R[7];
+        const double r2 = r == 0 ? R[2] : r == 1 ? R[5] : R[8];
+        tnew = r0 * st->Trans[c] + r1 * st->Trans[4 + c] + r2 * st->Trans[8 + c];
+        if (c == 3) tnew += (r == 0 ? x[3] : r == 1 ? x[4] : x[5]);
+    }
+    wave_lds_sync();
+    if (t < 12) st->Trans[t] = tnew;
+    if (t < kNumSums) st->S[t] = shS[t];
+    if (t != 0) return;
+
+    if (!ok) st->status = 4;   // SVICP_ERR_SINGULAR
 #pragma unroll
     for (int k = 0; k < 9; ++k) st->R[k] = R[k];
-    st->T[0] = X3; st->T[1] = X4; st->T[2] = X5;
-
-    // Trans = [R T; 0 1] * Trans
-    double Tr[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Tr[k] = st->Trans[k];
-    const double Tv[3] = { X3, X4, X5 };
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            double s = R[3 * r] * Tr[c] + R[3 * r + 1] * Tr[4 + c] + R[3 * r + 2] * Tr[8 + c];
-            if (c == 3) s += Tv[r];
-            st->Trans[4 * r + c] = s;
-        }
-
-    const double step = sqrt(X0 * X0 + X1 * X1 + X2 * X2 + X3 * X3 + X4 * X4 + X5 * X5);
+    st->T[0] = x[3]; st->T[1] = x[4]; st->T[2] = x[5];
+    const double step = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3] + x[4] * x[4] +
+                             x[5] * x[5]);
     st->S[30] = step;
     if (X_hist) {
-        X_hist[6 * iter + 0] = X0; X_hist[6 * iter + 1] = X1; X_hist[6 * iter + 2] = X2;
-        X_hist[6 * iter + 3] = X3; X_hist[6 * iter + 4] = X4; X_hist[6 * iter + 5] = X5;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) X_hist[6 * iter + r] = x[r];
     }
     if (info_hist) {
-        info_hist[4 * iter + 0] = S[27];
-        info_hist[4 * iter + 1] = S[28];
+        info_hist[4 * iter + 0] = shS[27];
+        info_hist[4 * iter + 1] = shS[28];
         info_hist[4 * iter + 2] = step;
-        info_hist[4 * iter + 3] = S[29];
+        info_hist[4 * iter + 3] = shS[29];
     }
 }
 
-// Sums the per-block partials (value-major [32][nb]) in a fixed order, then
-// either solves (sum_out == nullptr) or hands the 32 sums to the caller.
-__global__ __launch_bounds__(1024) void reduce_solve_kernel(const double *__restrict__ partials,
-                                                            int nb, IcpState *st, double *X_hist,
-                                                            double *info_hist, int iter,
-                                                            double *sum_out)
+// ------------------------------------------------------------------------
+// The iteration kernel: one launch per ICP iteration, one 1024-point tile of
+// the source per 256-thread block.
+//
+//  0. (APPLY) the first wave solves the previous iteration's 6x6 system from
+//     its 32 sums and forms R, T (CPoint2PlaneICP.cpp:109-119); every block does
+//     this redundantly, so no separate solve launch and no broadcast is needed.
+//     The block of tile 0 also records X and accumulates the 4x4 transform
+//     (CPoint2PlaneICP.cpp:36-39, :52-55).
+//  1. Every point is updated (CPoint2PlaneICP.cpp:42-50: fp64 math, one rounding
+//     to fp32).  With CERTIFY the kernel then tries to prove that the point's
+//     correspondence of the previous iteration still holds: a point that moved
+//     by delta has every other target point at least lb - delta away (triangle
+//     inequality); if its distance to the remembered neighbour is smaller than
+//     that, the neighbour is still the unique nearest one and no search is
+//     needed.  The bounds carry 1e-5 of relative slack, far more than fp32
+//     rounding of the distances, so the correspondence is the one a full search
+//     returns, bit for bit.  Proven points are accumulated from the remembered
+//     target point and normal: pure streaming, no gather.
+//  2. The remaining points are queued in LDS in a fixed order and searched by
+//     the whole block (CPoint2PlaneICP.cpp:65-67); what the search finds is
+//     remembered for the next iteration.
+//  3. Block sums of the 30 accumulators go to row `tile` of the partials.
+// ------------------------------------------------------------------------
+template <bool APPLY, bool CERTIFY, int CH>
+__global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
+    GridDesc g, const float *__restrict__ sx_in, const float *__restrict__ sy_in,
+    const float *__restrict__ sz_in, float *__restrict__ sx_out, float *__restrict__ sy_out,
+    float *__restrict__ sz_out, int n, const double *__restrict__ prev_sums, IcpState *st,
+    double *X_hist, double *info_hist, int iter, CohParams cp, PointState ps,
+    double *__restrict__ partials)
 {
-    // thread t sums value v = t / 32 over blocks (t % 32), (t % 32) + 32, ...:
-    // all loads of a thread are independent, the 32 threads of a value read
-    // consecutive doubles, and the order of additions is fixed
-    __shared__ double fin[kNumSums];
-    const int v = threadIdx.x >> 5, sub = threadIdx.x & 31;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    const double *row = partials + (size_t)v * nb;
-    int b = sub;
-    for (; b + 96 < nb; b += 128) {
-        s0 += row[b]; s1 += row[b + 32]; s2 += row[b + 64]; s3 += row[b + 96];
+    __shared__ float4 queue[kItTile];                 // {x, y, z, index in tile}
+    __shared__ double red[kItThreads / 64][kNumSums];
+    __shared__ int wcount[kItHalves * kItPoints][kItThreads / 64];
+    __shared__ double shRT[12];
+
+    // blocks that share an XCD (blockIdx % 8 equal) take neighbouring tiles,
+    // so each XCD's L2 sees one contiguous stretch of the Morton-ordered source
+    const int nb = (int)gridDim.x;
+    const int q8 = nb >> 3, r8 = nb & 7;
+    const int xcd = (int)blockIdx.x & 7, within = (int)blockIdx.x >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const long long tile0 = (long long)tile * kItTile;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+    double R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1, T0 = 0, T1 = 0,
+           T2 = 0;
+    if (APPLY) {
+        if (wv == 0) solve_and_update(prev_sums, st, X_hist, info_hist, iter - 1, tile == 0, shRT);
+        __syncthreads();
+        R0 = shRT[0]; R1 = shRT[1]; R2 = shRT[2]; R3 = shRT[3]; R4 = shRT[4]; R5 = shRT[5];
+        R6 = shRT[6]; R7 = shRT[7]; R8 = shRT[8]; T0 = shRT[9]; T1 = shRT[10]; T2 = shRT[11];
     }
-    for (; b < nb; b += 32) s0 += row[b];
-    double s = (s0 + s1) + (s2 + s3);
+
+    double acc[30];
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (sub == 0) {
-        fin[v] = s;
-        if (sum_out) sum_out[v] = s; else st->S[v] = s;
+    for (int v = 0; v < 30; ++v) acc[v] = 0.0;
+
+    // ---- pass 1 ----
+    unsigned queued_bits = 0;       // bit (h * kItPoints + p): that point needs a search
+    int my_rank[kItHalves * kItPoints];
+    float qx[kItHalves * kItPoints], qy[kItHalves * kItPoints], qz[kItHalves * kItPoints];
+#pragma unroll
+    for (int h = 0; h < kItHalves; ++h) {
+        float px[kItPoints], py[kItPoints], pz[kItPoints], lb[kItPoints];
+        float4 tp[kItPoints], nv[kItPoints];
+        bool live[kItPoints];
+        // all loads of the half tile are issued before anything waits on them
+#pragma unroll
+        for (int p = 0; p < kItPoints; ++p) {
+            const long long i = tile0 + (h * kItPoints + p) * kItThreads + (int)threadIdx.x;
+            live[p] = i < n;
+            const long long ic = live[p] ? i : 0;
+            px[p] = sx_in[ic]; py[p] = sy_in[ic]; pz[p] = sz_in[ic];
+            if (CERTIFY) { tp[p] = ps.tp[ic]; nv[p] = ps.nv[ic]; lb[p] = ps.lb[ic]; }
+        }
+#pragma unroll
+        for (int p = 0; p < kItPoints; ++p) {
+            const long long i = tile0 + (h * kItPoints + p) * kItThreads + (int)threadIdx.x;
+            const float ox = px[p], oy = py[p], oz = pz[p];
+            if (APPLY) {
+                // ((R0*x + R1*y) + R2*z) + T0 in fp64, no contraction, one rounding to fp32
+                double dx = (double)ox, dy = (double)oy, dz = (double)oz;
+                px[p] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R0, dx), __dmul_rn(R1, dy)), __dmul_rn(R2, dz)), T0);
+                py[p] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R3, dx), __dmul_rn(R4, dy)), __dmul_rn(R5, dz)), T1);
+                pz[p] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R6, dx), __dmul_rn(R7, dy)), __dmul_rn(R8, dz)), T2);
+                // in place the store can be skipped for a point that did not move
+                const bool moved = px[p] != ox || py[p] != oy || pz[p] != oz;
+                if (live[p] && (moved || sx_in != sx_out)) {
+                    sx_out[i] = px[p]; sy_out[i] = py[p]; sz_out[i] = pz[p];
+                }
+            }
+            bool need_search = live[p];
+            if (CERTIFY) {
+                float mx = px[p] - ox, my = py[p] - oy, mz = pz[p] - oz;
+                float m2 = mx * mx + my * my + mz * mz;
+                float lbn = lb[p];
+                if (m2 > 0.f) lbn = (lbn - sqrtf(m2) * 1.00001f) * 0.99999f;
+                const int pos = __float_as_int(tp[p].w);
+                float dx = px[p] - tp[p].x, dy = py[p] - tp[p].y, dz = pz[p] - tp[p].z;
+                float d2 = __fmul_rn(dx, dx);
+                d2 = __fadd_rn(d2, __fmul_rn(dy, dy));
+                d2 = __fadd_rn(d2, __fmul_rn(dz, dz));
+                // sqrt(d2) * (1 + 1e-5) < lbn, compared as squares
+                const bool proven_nn = pos >= 0 && lbn > 0.f && d2 * 1.00003f < lbn * lbn;
+                const bool proven_none = pos < 0 && lbn > cp.root_hi;
+                need_search = live[p] && !(proven_nn || proven_none);
+                if (live[p] && !need_search && m2 > 0.f) ps.lb[i] = lbn;
+                if (live[p] && proven_nn && d2 <= cp.thr)
+                    accumulate_point(acc, px[p], py[p], pz[p], d2, cp.thr, tp[p].x, tp[p].y,
+                                     tp[p].z, nv[p].x, nv[p].y, nv[p].z);
+            }
+            // position of this point among the queued ones of its wave
+            const unsigned long long mask = __ballot(need_search);
+            const int slot = h * kItPoints + p;
+            my_rank[slot] = __popcll(mask & ((1ull << lane) - 1ull));
+            if (need_search) queued_bits |= 1u << slot;
+            if (lane == 0) wcount[slot][wv] = __popcll(mask);
+            qx[slot] = px[p]; qy[slot] = py[p]; qz[slot] = pz[p];
+        }
     }
-    if (sum_out) return;
     __syncthreads();
-    solve_and_update(fin, st, X_hist, info_hist, iter);
+    // fixed order of the queue: by pass, then by thread
+    int total = 0;
+#pragma unroll
+    for (int slot = 0; slot < kItHalves * kItPoints; ++slot) {
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < kItThreads / 64; ++w) {
+            const int c = wcount[slot][w];
+            before += w < wv ? c : 0;
+            all += c;
+        }
+        if (queued_bits & (1u << slot))
+            queue[total + before + my_rank[slot]] = make_float4(
+                qx[slot], qy[slot], qz[slot], __int_as_float(slot * kItThreads + (int)threadIdx.x));
+        total += all;
+    }
+    __syncthreads();
+
+    // ---- pass 2: search the queued points ----
+    for (int q = threadIdx.x; q < total; q += kItThreads) {
+        const float4 e = queue[q];
+        const long long i = tile0 + __float_as_int(e.w);
+        float best, second; int bpos, bidx;
+        nn_capped<CH, true>(g, e.x, e.y, e.z, best, bpos, bidx, &second);
+        float4 tp = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float lbn = cp.cov * 0.99999f;
+        if (bpos >= 0 && sqrtf(best) * 1.00001f <= cp.cov) {
+            // no unprobed point can be nearer: bpos is the nearest neighbour
+            float4 t = g.pts[bpos];
+            const size_t o = 3 * (size_t)bpos;
+            tp = make_float4(t.x, t.y, t.z, __int_as_float(bpos));
+            nv = make_float4(g.nrm[o], g.nrm[o + 1], g.nrm[o + 2], 0.f);
+            lbn = fminf(sqrtf(second) * 0.99999f, lbn);
+            if (best <= cp.thr)
+                accumulate_point(acc, e.x, e.y, e.z, best, cp.thr, t.x, t.y, t.z, nv.x, nv.y, nv.z);
+        }
+        ps.tp[i] = tp;
+        ps.nv[i] = nv;
+        ps.lb[i] = lbn;
+    }
+
+    const double s = block_sum_30(acc, red);
+    if (threadIdx.x < kNumSums) partials[(size_t)threadIdx.x * nb + tile] = s;
 }
 
-// Solve from sums that were reduced elsewhere (the all-reduced block of a
-// sharded registration).
-__global__ void solve_from_sums_kernel(const double *__restrict__ sums, IcpState *st,
-                                       double *X_hist, double *info_hist, int iter)
+// Sums one row of the tile partials (value-major [32][nb]) per block, in a
+// fixed order.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restrict__ partials,
+                                                          int nb, double *__restrict__ sums)
 {
-    __shared__ double fin[kNumSums];
-    if (blockIdx.x != 0) return;
-    if (threadIdx.x < kNumSums) {
-        fin[threadIdx.x] = sums[threadIdx.x];
-        st->S[threadIdx.x] = sums[threadIdx.x];
+    __shared__ double red[4];
+    const int v = blockIdx.x;
+    const double *row = partials + (size_t)v * nb;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = threadIdx.x;
+    for (; b + 768 < nb; b += 1024) {
+        s0 += row[b]; s1 += row[b + 256]; s2 += row[b + 512]; s3 += row[b + 768];
     }
+    for (; b < nb; b += 256) s0 += row[b];
+    double s = wave_sum_lane63((s0 + s1) + (s2 + s3));
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    solve_and_update(fin, st, X_hist, info_hist, iter);
+    if (threadIdx.x == 0) sums[v] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One wave: solve from the 32 sums and record the result (the last iteration
+// of a run has no following iteration kernel to do it).
+__global__ __launch_bounds__(64) void solve_kernel(const double *__restrict__ sums, IcpState *st,
+                                                   double *X_hist, double *info_hist, int iter)
+{
+    __shared__ double rt[12];
+    solve_and_update(sums, st, X_hist, info_hist, iter, true, rt);
 }
 
 __global__ void reset_state_kernel(IcpState *st)
@@ -455,7 +740,7 @@ __global__ void reset_state_kernel(IcpState *st)
 // radius only, as the iteration loop searches.  EXACT = true: unbounded;
 // queries the ring search cannot settle are queued for the brute-force pass.
 // ------------------------------------------------------------------------
-template <bool EXACT>
+template <bool EXACT, int CH>
 __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
     GridDesc g, const float *__restrict__ qx_, const float *__restrict__ qy_,
     const float *__restrict__ qz_, const int *__restrict__ perm, int n, float thr,
@@ -466,7 +751,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
          i += (long long)gridDim.x * kBlockThreads) {
         float qx = qx_[i], qy = qy_[i], qz = qz_[i];
         float best; int bpos, bidx;
-        nn_capped(g, qx, qy, qz, best, bpos, bidx);
+        nn_capped<CH>(g, qx, qy, qz, best, bpos, bidx);
         const long long o = perm ? perm[i] : i;
         if (!EXACT) {
             bool hit = bpos >= 0 && best <= thr;

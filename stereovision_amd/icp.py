@@ -174,6 +174,14 @@ class Context:
         self._check(self._lib.svicp_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def iteration_times(self):
+        """Per-iteration (fused_ms, solve_ms) arrays of the last timed run."""
+        n = self.kernel_times()[2]
+        a = np.zeros(n, np.float64)
+        b = np.zeros(n, np.float64)
+        self._check(self._lib.svicp_iteration_times(self._h, _dp(a), _dp(b)))
+        return a, b
+
     def time_nn(self, exact=False, reps=10):
         ms = C.c_double()
         self._check(self._lib.svicp_time_nn(self._h, 1 if exact else 0, int(reps), C.byref(ms)))

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     o = _lib.Options()
     assert _lib.load().svicp_default_options(ctypes.byref(o)) == 0
     assert o.dist_threshold == 5.0 and o.normals_k == 20        # CPoint2PlaneICP.cpp:68,125
-    assert o.use_graph == 1 and o.sort_source == 1
+    assert o.use_graph == 1 and o.sort_source == 1 and o.coherent == 1
 
 
 def test_no_device_is_an_error_not_a_fallback():
