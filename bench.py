@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--sharded-side", type=int, default=4096,
                     help="side of the pair of the sharded leg; 0 disables the leg")
-    ap.add_argument("--cpu-iters", type=int, default=8,
+    ap.add_argument("--cpu-iters", type=int, default=30,
                     help="iterations of the CPU baseline sample; 0 disables it")
     return ap.parse_args()
 
@@ -89,21 +89,38 @@ def main():
     # ---- per-kernel durations: the same steps, eager, HIP events on the
     # library's stream around every launch -------------------------------
     ctx.set_options(time_kernels=1)
-    fused, solve = [], []
+    fused, reduce_, per_iter = [], [], []
     for _ in range(max(2, min(args.steps, 5))):
         ctx.run(args.iters)
         f, s, _ = ctx.kernel_times()
         fused.append(f)
-        solve.append(s)
+        reduce_.append(s)
+        per_iter.append(ctx.iteration_times()[0])
     ctx.set_options(time_kernels=0)
-    fused_ms, solve_ms = float(np.mean(fused)), float(np.mean(solve))
-    # algorithmic bytes of one launch of the fused kernel: source read + write
-    # (24 B/pt), target xyz + normal + index (28 B/pt), each touched once
+    fused_ms, reduce_ms = float(np.mean(fused)), float(np.mean(reduce_))
+    per_iter = np.mean(np.stack(per_iter), axis=0)
+    # algorithmic bytes of one launch of the iteration kernel: source read + write
+    # (24 B/pt), target xyz + index + normal (28 B/pt), each touched once
     bytes_fused = 24.0 * n + 28.0 * len(tgt)
     achieved = bytes_fused / (fused_ms * 1e-3) / 1e9
+    slowest_ms = float(per_iter.max())            # a launch that searches every point
     nn_capped_ms = ctx.time_nn(exact=False, reps=20)
     nn_exact_ms = ctx.time_nn(exact=True, reps=20)
     bytes_nn = 20.0 * n + 16.0 * len(tgt)
+    # without the shortcut for points whose correspondence provably did not change
+    ctx.set_options(coherent=0)
+    ctx.run(args.iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(max(2, args.steps // 2)):
+        ctx.run(args.iters)
+    full_search_value = max(2, args.steps // 2) * args.iters / (time.perf_counter() - t0)
+    ctx.set_options(coherent=1)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            traffic = json.load(fh).get("icp_iterate_kernel_bytes_per_launch")
 
     # ---- sharded leg ----------------------------------------------------
     sharded = None
@@ -155,7 +172,7 @@ def main():
         Xg, _ = ctx.history()
         cpu = {
             "value": args.cpu_iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": f"first {args.cpu_iters} of {args.iters} iterations of the same "
+            "sample": f"{args.cpu_iters} of {args.iters} iterations of the same "
                       f"{n}-point pair, kd-tree build excluded, restated reference "
                       "(oracle/icp_oracle.c; the reference needs FLANN+Eigen and cannot be built)",
             "host_cpus": os.cpu_count(),
@@ -183,14 +200,19 @@ def main():
                 "points": n, "iters_per_step": args.iters,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "icp_accumulate_kernel",
+                "bound": "hbm", "kernel": "icp_iterate_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": bytes_fused, "launch_ms": fused_ms,
+                "launches_averaged": args.iters,
+                "slowest_launch_ms": slowest_ms,
+                "frac_slowest_launch": bytes_fused / (slowest_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             "cpu_baseline": cpu,
-            "kernels_ms": {"icp_accumulate": fused_ms, "reduce_solve": solve_ms,
+            "kernels_ms": {"icp_iterate": fused_ms, "reduce_rows": reduce_ms,
+                           "icp_iterate_per_iteration": [round(float(x), 5) for x in per_iter],
                            "nn1_capped": nn_capped_ms, "nn1_exact": nn_exact_ms},
+            "value_searching_every_point_every_iteration": full_search_value,
             "nn_queries_per_s": {"capped": n / (nn_capped_ms * 1e-3),
                                  "exact": n / (nn_exact_ms * 1e-3),
                                  "capped_GBs": bytes_nn / (nn_capped_ms * 1e-3) / 1e9},

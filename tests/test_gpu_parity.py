@@ -125,6 +125,58 @@ def test_knn_class(pair, po):
     assert np.array_equal(idx, oi) and np.array_equal(d2, od)
 
 
+def test_cpp_driver_runs_like_test_cpp(pair, tmp_path):
+    """examples/test.cpp is the reference's test.cpp with only the include lines
+    changed; it must print the golden transform (test.cpp:14-29)."""
+    import os
+    import subprocess
+    ref, src, gold = pair
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "test_icp")
+    assert os.path.exists(exe), "build it with make -C stereovision_amd/csrc example"
+    np.savetxt(tmp_path / "17.txt", ref, fmt="%.8f")
+    np.savetxt(tmp_path / "15.txt", src, fmt="%.8f")
+    out = subprocess.run([exe, str(tmp_path / "17.txt"), str(tmp_path / "15.txt")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    at = lines.index("Current Transformation:")
+    T = np.array([[float(v) for v in lines[at + 1 + r].split()] for r in range(4)])
+    assert np.abs(T - gold["trans5"]).max() < 1e-5          # printed with 6 significant digits
+    assert "Euler Angle X Y Z:" in out.stdout and "searchint spend" in out.stdout
+    e = lines.index("Euler Angle X Y Z: ")
+    ang = [float(lines[e + 1 + k]) for k in range(3)]
+    # the bundled pair differs by Rx(1 deg) Ry(0.5 deg); eulerAngles(0,1,2) reports R = Rx Ry Rz
+    assert abs(abs(ang[0]) - 1.0) < 1e-2 or abs(abs(ang[0]) - 179.0) < 1e-2
+
+
+def test_coherent_search_matches_full_search(ctx, pair):
+    """Skipping the search for points whose old correspondence is provably still
+    the nearest neighbour must not change anything."""
+    from stereovision_amd import synth
+    ref, src, gold = pair
+    cases = [(ref, gold["normals"], src)]
+    tgt, nrm, s, _ = synth.make_pair(100)
+    cases.append((tgt, nrm, s))
+    for tgt, nrm, s in cases:
+        res = []
+        for coh in (0, 1):
+            ctx.set_options(coherent=coh)
+            ctx.set_target(tgt, nrm)
+            ctx.set_source(s)
+            T, info = ctx.run(12)
+            X, I = ctx.history()
+            res.append((T, X, I, ctx.get_source(), ctx.correspondences()))
+        (T0, X0, I0, s0, c0), (T1, X1, I1, s1, c1) = res
+        assert np.abs(X0 - X1).max() < 1e-11 and np.abs(T0 - T1).max() < 1e-11
+        assert np.array_equal(I0[:, 0], I1[:, 0])              # same inlier counts every iteration
+        assert np.abs(s0 - s1).max() <= 4e-5
+        same = (s0 == s1).all(axis=1)
+        assert same.mean() > 0.999
+        assert np.array_equal(c0[0][same], c1[0][same]) and np.array_equal(c0[1][same], c1[1][same])
+    ctx.set_options(coherent=1)
+
+
 # ---------------------------------------------------------------- synthetic
 @pytest.mark.parametrize("side", [32, 100, 256])
 def test_synthetic_pair_matches_oracle(ctx, po, side):
