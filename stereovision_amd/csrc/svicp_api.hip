@@ -66,7 +66,7 @@ struct svicp_ctx {
     DevBuf knn_idx, knn_d2, unresolved, n_unres;
 
     // iteration loop
-    DevBuf partials, sums, state, xhist, ihist;
+    DevBuf partials, totals, deltas, state, xhist, ihist;
     IcpState *h_state = nullptr;   // pinned
     int hist_cap = 0, last_iters = 0;
     int nb = 0, chunk = 0;
@@ -80,7 +80,6 @@ struct svicp_ctx {
     int timed_launches = 0;
 
     int shard_iter = 0;
-    int variant = 4;   // candidates loaded per chunk in the 1-NN walk
 };
 
 namespace {
@@ -233,12 +232,13 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
     }
     HIPCHK(ctx->partials.reserve(sizeof(double) * kNumSums * nb));
     HIPCHK(ctx->state.reserve(sizeof(IcpState)));
-    HIPCHK(ctx->sums.reserve(sizeof(double) * kNumSums));
     if (iters > ctx->hist_cap) {
         drop_graph(ctx);
         int cap = std::max(iters, 64);
         HIPCHK(ctx->xhist.reserve(sizeof(double) * 6 * cap));
         HIPCHK(ctx->ihist.reserve(sizeof(double) * 4 * cap));
+        HIPCHK(ctx->totals.reserve(sizeof(double) * kNumSums * (cap + 1)));
+        HIPCHK(ctx->deltas.reserve(sizeof(double) * kNumSums * cap));
         ctx->hist_cap = cap;
     }
     if (!ctx->h_state) HIPCHK(hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState), 0));
@@ -260,24 +260,24 @@ void launch_iteration(svicp_ctx *ctx, int k, double *partials)
     float *wx = ctx->wx.as<float>(), *wy = ctx->wy.as<float>(), *wz = ctx->wz.as<float>();
     const float *x0 = ctx->sx0.as<float>(), *y0 = ctx->sy0.as<float>(), *z0 = ctx->sz0.as<float>();
     IcpState *state = ctx->state.as<IcpState>();
-    const double *sums = ctx->sums.as<double>();
+    double *tot = ctx->totals.as<double>(), *del = ctx->deltas.as<double>();
     double *xh = ctx->xhist.as<double>(), *ih = ctx->ihist.as<double>();
     const dim3 grid(ctx->nb), block(kItThreads);
     const int n = (int)ctx->n;
     if (k == 0) {
         hipLaunchKernelGGL((icp_iterate_kernel<false, false, 4>), grid, block, 0, ctx->stream,
-                           ctx->g, x0, y0, z0, wx, wy, wz, n, sums, state, xh, ih, k, cp, ps,
+                           ctx->g, x0, y0, z0, wx, wy, wz, n, tot, del, state, xh, ih, k, cp, ps,
                            partials);
         return;
     }
     const float *ix = k == 1 ? x0 : wx, *iy = k == 1 ? y0 : wy, *iz = k == 1 ? z0 : wz;
     if (ctx->opt.coherent)
         hipLaunchKernelGGL((icp_iterate_kernel<true, true, 4>), grid, block, 0, ctx->stream,
-                           ctx->g, ix, iy, iz, wx, wy, wz, n, sums, state, xh, ih, k, cp, ps,
+                           ctx->g, ix, iy, iz, wx, wy, wz, n, tot, del, state, xh, ih, k, cp, ps,
                            partials);
     else
         hipLaunchKernelGGL((icp_iterate_kernel<true, false, 4>), grid, block, 0, ctx->stream,
-                           ctx->g, ix, iy, iz, wx, wy, wz, n, sums, state, xh, ih, k, cp, ps,
+                           ctx->g, ix, iy, iz, wx, wy, wz, n, tot, del, state, xh, ih, k, cp, ps,
                            partials);
 }
 
@@ -286,22 +286,22 @@ int enqueue_loop(svicp_ctx *ctx, int iters, bool timed)
     hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(64), 0, ctx->stream,
                        ctx->state.as<IcpState>());
     LAUNCHCHK("reset_state_kernel");
+    // totals row 0 (the sums "before iteration 0") and every delta row start at zero
+    HIPCHK(hipMemsetAsync(ctx->totals.p, 0, sizeof(double) * kNumSums, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->deltas.p, 0, sizeof(double) * kNumSums * iters, ctx->stream));
     for (int k = 0; k < iters; ++k) {
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 0], ctx->stream));
         launch_iteration(ctx, k, ctx->partials.as<double>());
         LAUNCHCHK("icp_iterate_kernel");
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 1], ctx->stream));
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 2], ctx->stream));
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(30), dim3(256), 0, ctx->stream,
-                           ctx->partials.as<double>(), ctx->nb, ctx->sums.as<double>());
-        LAUNCHCHK("reduce_rows_kernel");
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 3], ctx->stream));
     }
     // the last iteration's system is solved here; the others were solved at the
     // start of the following iteration's kernel
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->sums.as<double>(),
-                       ctx->state.as<IcpState>(), ctx->xhist.as<double>(),
-                       ctx->ihist.as<double>(), iters - 1);
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->totals.as<double>(),
+                       ctx->deltas.as<double>(), ctx->state.as<IcpState>(),
+                       ctx->xhist.as<double>(), ctx->ihist.as<double>(), iters - 1);
     LAUNCHCHK("solve_kernel");
     return SVICP_OK;
 }
@@ -364,7 +364,6 @@ int svicp_create(int device_id, svicp_ctx **out)
     ctx->device = device_id;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     svicp_default_options(&ctx->opt);
-    if (const char *v = std::getenv("SVICP_VARIANT")) ctx->variant = std::atoi(v);
     e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, SVICP_ERR_HIP, "hipStreamCreate", e); }
     ctx->stream = ctx->own_stream;
@@ -384,7 +383,7 @@ int svicp_destroy(svicp_ctx *ctx)
                        &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->perm, &ctx->tmp_aos, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
                        &ctx->vals_b, &ctx->marks, &ctx->ranks, &ctx->block_of_rank,
                        &ctx->sort_tmp, &ctx->bbox6, &ctx->knn_idx, &ctx->knn_d2,
-                       &ctx->unresolved, &ctx->n_unres, &ctx->partials, &ctx->sums, &ctx->state, &ctx->xhist,
+                       &ctx->unresolved, &ctx->n_unres, &ctx->partials, &ctx->totals, &ctx->deltas, &ctx->state, &ctx->xhist,
                        &ctx->ihist };
     for (DevBuf *b : bufs) b->release();
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -825,11 +824,13 @@ int svicp_shard_begin(svicp_ctx *ctx)
     if (!ctx->have_target || !ctx->have_source)
         return fail(ctx, SVICP_ERR_ARG, "svicp_shard_begin: set the target and the source first");
     HIPCHK(hipSetDevice(ctx->device));
-    int rc = ensure_iteration_buffers(ctx, 64);
+    int rc = ensure_iteration_buffers(ctx, 1024);   // room for this many sharded iterations
     if (rc) return rc;
     hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(64), 0, ctx->stream,
                        ctx->state.as<IcpState>());
     LAUNCHCHK("reset_state_kernel");
+    HIPCHK(hipMemsetAsync(ctx->totals.p, 0, sizeof(double) * kNumSums, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->deltas.p, 0, sizeof(double) * kNumSums * ctx->hist_cap, ctx->stream));
     ctx->shard_iter = 0;
     ctx->cur = 0;
     return SVICP_OK;
@@ -839,14 +840,14 @@ int svicp_shard_accumulate(svicp_ctx *ctx, double *dev_partial32)
 {
     if (!ctx || !dev_partial32) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_accumulate: NULL argument");
     HIPCHK(hipSetDevice(ctx->device));
-    int rc = ensure_iteration_buffers(ctx, ctx->shard_iter + 1);
-    if (rc) return rc;
-    launch_iteration(ctx, ctx->shard_iter, ctx->partials.as<double>());
+    if (ctx->shard_iter >= ctx->hist_cap)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_shard_accumulate: too many iterations since svicp_shard_begin");
+    const int k = ctx->shard_iter;
+    launch_iteration(ctx, k, ctx->partials.as<double>());
     LAUNCHCHK("icp_iterate_kernel");
-    HIPCHK(hipMemsetAsync(dev_partial32, 0, sizeof(double) * kNumSums, ctx->stream));
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(30), dim3(256), 0, ctx->stream,
-                       ctx->partials.as<double>(), ctx->nb, dev_partial32);
-    LAUNCHCHK("reduce_rows_kernel");
+    // this rank's change of the sums in iteration k
+    HIPCHK(hipMemcpyAsync(dev_partial32, ctx->deltas.as<double>() + (size_t)k * kNumSums,
+                          sizeof(double) * kNumSums, hipMemcpyDeviceToDevice, ctx->stream));
     if (ctx->shard_iter >= 1) ctx->cur = 1;
     return SVICP_OK;
 }
@@ -855,9 +856,10 @@ int svicp_shard_update(svicp_ctx *ctx, const double *dev_sum32)
 {
     if (!ctx || !dev_sum32) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_update: NULL argument");
     HIPCHK(hipSetDevice(ctx->device));
-    // the sum is consumed by the next svicp_shard_accumulate (or _finish)
-    HIPCHK(hipMemcpyAsync(ctx->sums.p, dev_sum32, sizeof(double) * kNumSums,
-                          hipMemcpyDeviceToDevice, ctx->stream));
+    // the summed change replaces this rank's own; the next svicp_shard_accumulate
+    // (or _finish) adds it to the running totals and solves
+    HIPCHK(hipMemcpyAsync(ctx->deltas.as<double>() + (size_t)ctx->shard_iter * kNumSums, dev_sum32,
+                          sizeof(double) * kNumSums, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->shard_iter++;
     ctx->last_iters = ctx->shard_iter;
     return SVICP_OK;
@@ -868,9 +870,9 @@ int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info)
     if (!ctx || !T_out) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_finish: NULL argument");
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->shard_iter < 1) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_finish: no iteration was run");
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->sums.as<double>(),
-                       ctx->state.as<IcpState>(), ctx->xhist.as<double>(),
-                       ctx->ihist.as<double>(), ctx->shard_iter - 1);
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->totals.as<double>(),
+                       ctx->deltas.as<double>(), ctx->state.as<IcpState>(),
+                       ctx->xhist.as<double>(), ctx->ihist.as<double>(), ctx->shard_iter - 1);
     LAUNCHCHK("solve_kernel");
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->state.p, sizeof(IcpState), hipMemcpyDeviceToHost,
                           ctx->stream));

@@ -267,7 +267,7 @@ __device__ __forceinline__ double wave_sum_lane63(double v)
 // :65-79 (1-NN, weight) and :85-109 (row assembly, weighted normal equations).
 // ------------------------------------------------------------------------
 constexpr int kItThreads = 256;                  // threads per block of the iteration kernels
-constexpr int kItPoints = 2;                     // points a thread holds at once
+constexpr int kItPoints = 2;                     // (kItPoints * kItHalves points per thread)
 constexpr int kItHalves = 2;                     // passes of kItPoints per tile
 constexpr int kItTile = kItThreads * kItPoints * kItHalves;   // source points per block
 
@@ -395,91 +395,100 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// Wave-parallel solve, called by ONE full wave (64 lanes).  S: the 32 sums
-// (global or LDS).  Results: R (9) and T (3) to out_rt (LDS); when `record`,
-// also the state, the accumulated transform and the history rows.
+// Value of `v` in lane `lane` (a constant), the same in every lane afterwards.
+__device__ __forceinline__ double lane_bcast(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Wave-parallel solve, called by ONE full wave (64 lanes).  The 32 sums are
+// base[] + delta[] (global memory).  Results: R (9) and T (3) to out_rt (LDS);
+// when `record`, also the sums to totals[], the state, the accumulated
+// transform and the history rows.
 //
 // Cholesky of the diagonally scaled matrix with the right-hand side carried as
-// a seventh row, so the forward substitution falls out of the factorisation:
-// lane r owns row r; every lane recomputes the pivot of the current column.
+// a seventh row, so the forward substitution falls out of the factorisation.
+// Lane r (r < 7) keeps row r in registers; what other rows need of it travels
+// by lane broadcasts, so there is no LDS or memory round trip inside the
+// factorisation.  Lanes >= 7 run the same instructions on values nobody reads.
 // Restates CPoint2PlaneICP.cpp:109 (X), :111-119 (R = Rz*Ry*Rx, T) and
 // :36-39 / :52-55 (Trans = [R T; 0 1] * Trans).
-__device__ inline void solve_and_update(const double *S, IcpState *st, double *X_hist,
-                                        double *info_hist, int iter, bool record, double *out_rt)
+__device__ inline void solve_and_update(const double *base, const double *delta, double *totals,
+                                        IcpState *st, double *X_hist, double *info_hist,
+                                        int iter, bool record, double *out_rt)
 {
-    __shared__ double M[7][8];     // rows 0-5: scaled matrix / factor, row 6: scaled rhs / y
-    __shared__ double shS[kNumSums];
-    __shared__ double shD[8];      // scaling d = diag^-1/2
-    __shared__ double shSC[8];
     const int t = threadIdx.x & 63;
+    const int row = t < 7 ? t : 6;
     bool ok = true;
 
-    if (t < kNumSums) shS[t] = t < 30 ? S[t] : 0.0;
-    wave_lds_sync();
-    // upper triangle: element (r, c), r <= c, sits at r*6 - r(r-1)/2 + (c - r)
-    if (t < 6) {
-        const double a = shS[t * 6 - (t * (t - 1)) / 2];
-        shD[t] = (a > 1e-300 && a < 1e300) ? fast_rsqrt(a) : 0.0;
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 6; ++k) ok = ok && (shD[k] > 0.0);
-    if (t < 49) {
-        const int r = t / 7, c = t % 7;
-        if (r < 6 && c < 6) {
-            const int lo = r < c ? r : c, hi = r < c ? c : r;
-            M[r][c] = shS[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)] * shD[r] * shD[c];
-        } else if (r == 6 && c < 6) {
-            M[6][c] = shS[21 + c] * shD[c];
-        }
-    }
-    wave_lds_sync();
-
+    // running totals of the normal equations: the totals after the iteration
+    // before, plus what the tiles that changed since have added or taken away.
+    // Upper triangle: element (r, c), r <= c, sits at r*6 - r(r-1)/2 + (c - r).
+    double m[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        double piv = M[c][c];
-#pragma unroll
-        for (int k = 0; k < c; ++k) piv -= M[c][k] * M[c][k];
-        if (!(piv > 1e-14) || !(piv < 1e300)) { ok = false; piv = 1.0; }
-        const double inv = fast_rsqrt(piv);
-        double mine = 0.0;
-        if (t > c && t < 7) {
-            mine = M[t][c];
-#pragma unroll
-            for (int k = 0; k < c; ++k) mine -= M[t][k] * M[c][k];
-            mine *= inv;
-        }
-        wave_lds_sync();
-        if (t > c && t < 7) M[t][c] = mine;
-        if (t == c) { M[c][c] = piv * inv; M[c][7] = inv; }   // L_cc and its reciprocal
-        wave_lds_sync();
+        const int lo = row < c ? row : c, hi = row < c ? c : row;
+        const int at = row < 6 ? lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo) : 21 + c;
+        m[c] = base[at] + delta[at];
     }
-    // back substitution L^T x = y, every lane redundantly
+    double stat = 0.0;                      // lanes 0..31 also carry sum t for the record
+    if (t < kNumSums) stat = t < 30 ? base[t] + delta[t] : 0.0;
+    if (record && t < kNumSums) totals[t] = stat;
+
+    // scaling d = diag^-1/2
+    double d[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const double a = lane_bcast(m[c], c);
+        const bool good = a > 1e-300 && a < 1e300;
+        ok = ok && good;
+        d[c] = good ? fast_rsqrt(a) : 1.0;
+    }
+    double dmine = 1.0;                     // the rhs row is scaled by the columns only
+#pragma unroll
+    for (int c = 0; c < 6; ++c) dmine = (row == c) ? d[c] : dmine;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) m[c] = m[c] * dmine * d[c];
+
+    double inv[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        double lc[6];                       // row c of the factor, columns < c
+#pragma unroll
+        for (int k = 0; k < c; ++k) lc[k] = lane_bcast(m[k], c);
+        double v = m[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) v -= m[k] * lc[k];
+        double piv = lane_bcast(v, c);
+        if (!(piv > 1e-14) || !(piv < 1e300)) { ok = false; piv = 1.0; }
+        inv[c] = fast_rsqrt(piv);
+        m[c] = v * inv[c];                  // lane c: sqrt(piv); lanes > c: L[r][c]; lane 6: y[c]
+    }
+    // back substitution L^T x = y
     double x[6];
 #pragma unroll
     for (int r = 5; r >= 0; --r) {
-        double v = M[6][r];
+        double v = lane_bcast(m[r], 6);
 #pragma unroll
-        for (int k = r + 1; k < 6; ++k) v -= M[k][r] * x[k];
-        x[r] = v * M[r][7];
+        for (int k = r + 1; k < 6; ++k) v -= lane_bcast(m[r], k) * x[k];
+        x[r] = v * inv[r];
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-        x[r] *= shD[r];
+        x[r] *= d[r];
         if (!(fabs(x[r]) < 1e300)) ok = false;
     }
     if (!ok) {
 #pragma unroll
         for (int r = 0; r < 6; ++r) x[r] = 0.0;
     }
-    if (t < 3) {
-        double sn, cs;
-        sincos(t == 0 ? x[0] : t == 1 ? x[1] : x[2], &sn, &cs);
-        shSC[2 * t] = sn;
-        shSC[2 * t + 1] = cs;
-    }
-    wave_lds_sync();
-    const double sx = shSC[0], cx = shSC[1], sy = shSC[2], cy = shSC[3], sz = shSC[4], cz = shSC[5];
+    // the three angles' sines and cosines on three lanes at once
+    double sn, cs;
+    sincos(t == 0 ? x[0] : t == 1 ? x[1] : x[2], &sn, &cs);
+    const double sx = lane_bcast(sn, 0), cx = lane_bcast(cs, 0), sy = lane_bcast(sn, 1),
+                 cy = lane_bcast(cs, 1), sz = lane_bcast(sn, 2), cz = lane_bcast(cs, 2);
     // R = Rz(X2) * Ry(X1) * Rx(X0)
     const double R[9] = { cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
                           sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx,
@@ -503,7 +512,8 @@ __device__ inline void solve_and_update(const double *S, IcpState *st, double *X
     }
     wave_lds_sync();
     if (t < 12) st->Trans[t] = tnew;
-    if (t < kNumSums) st->S[t] = shS[t];
+    if (t < kNumSums) st->S[t] = stat;
+    const double s27 = lane_bcast(stat, 27), s28 = lane_bcast(stat, 28), s29 = lane_bcast(stat, 29);
     if (t != 0) return;
 
     if (!ok) st->status = 4;   // SVICP_ERR_SINGULAR
@@ -518,10 +528,10 @@ __device__ inline void solve_and_update(const double *S, IcpState *st, double *X
         for (int r = 0; r < 6; ++r) X_hist[6 * iter + r] = x[r];
     }
     if (info_hist) {
-        info_hist[4 * iter + 0] = shS[27];
-        info_hist[4 * iter + 1] = shS[28];
+        info_hist[4 * iter + 0] = s27;
+        info_hist[4 * iter + 1] = s28;
         info_hist[4 * iter + 2] = step;
-        info_hist[4 * iter + 3] = shS[29];
+        info_hist[4 * iter + 3] = s29;
     }
 }
 
@@ -547,19 +557,22 @@ __device__ inline void solve_and_update(const double *S, IcpState *st, double *X
 //  2. The remaining points are queued in LDS in a fixed order and searched by
 //     the whole block (CPoint2PlaneICP.cpp:65-67); what the search finds is
 //     remembered for the next iteration.
-//  3. Block sums of the 30 accumulators go to row `tile` of the partials.
+//  3. Block sums of the 30 accumulators replace row `tile` of the partials and
+//     their change is added to this iteration's delta sums, so no separate
+//     reduction launch is needed; a tile that was skipped adds nothing.
 // ------------------------------------------------------------------------
 template <bool APPLY, bool CERTIFY, int CH>
 __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     GridDesc g, const float *__restrict__ sx_in, const float *__restrict__ sy_in,
     const float *__restrict__ sz_in, float *__restrict__ sx_out, float *__restrict__ sy_out,
-    float *__restrict__ sz_out, int n, const double *__restrict__ prev_sums, IcpState *st,
-    double *X_hist, double *info_hist, int iter, CohParams cp, PointState ps,
+    float *__restrict__ sz_out, int n, double *__restrict__ totals, double *__restrict__ deltas,
+    IcpState *st, double *X_hist, double *info_hist, int iter, CohParams cp, PointState ps,
     double *__restrict__ partials)
 {
+    constexpr int NP = kItPoints * kItHalves;         // points per thread
     __shared__ float4 queue[kItTile];                 // {x, y, z, index in tile}
     __shared__ double red[kItThreads / 64][kNumSums];
-    __shared__ int wcount[kItHalves * kItPoints][kItThreads / 64];
+    __shared__ int wcount[NP][kItThreads / 64];
     __shared__ double shRT[12];
 
     // blocks that share an XCD (blockIdx % 8 equal) take neighbouring tiles,
@@ -570,103 +583,149 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
     const long long tile0 = (long long)tile * kItTile;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool in_place = sx_in == sx_out;
 
+    // ---- A: coordinates (and the tile's old sums) are requested first, so
+    // their latency runs under the solve ----
+    float px[NP], py[NP], pz[NP];
+    bool live[NP];
+#pragma unroll
+    for (int sl = 0; sl < NP; ++sl) {
+        const long long i = tile0 + sl * kItThreads + (int)threadIdx.x;
+        live[sl] = i < n;
+        const long long ic = live[sl] ? i : 0;
+        px[sl] = sx_in[ic]; py[sl] = sy_in[ic]; pz[sl] = sz_in[ic];
+    }
+    double old_row = 0.0;
+    if (APPLY && threadIdx.x < 30) old_row = partials[(size_t)threadIdx.x * nb + tile];
+
+    // ---- B: solve the previous iteration's system ----
     double R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1, T0 = 0, T1 = 0,
            T2 = 0;
     if (APPLY) {
-        if (wv == 0) solve_and_update(prev_sums, st, X_hist, info_hist, iter - 1, tile == 0, shRT);
+        // totals[k]: sums after iteration k - 1 (row 0 is zero); deltas[k]: changes made by iteration k
+        if (wv == 0)
+            solve_and_update(totals + (size_t)(iter - 1) * kNumSums,
+                             deltas + (size_t)(iter - 1) * kNumSums,
+                             totals + (size_t)iter * kNumSums, st, X_hist, info_hist, iter - 1,
+                             tile == 0, shRT);
         __syncthreads();
         R0 = shRT[0]; R1 = shRT[1]; R2 = shRT[2]; R3 = shRT[3]; R4 = shRT[4]; R5 = shRT[5];
         R6 = shRT[6]; R7 = shRT[7]; R8 = shRT[8]; T0 = shRT[9]; T1 = shRT[10]; T2 = shRT[11];
+    }
+
+    // ---- C: update (CPoint2PlaneICP.cpp:44-49) ----
+    float m2[NP];                 // squared displacement of the point
+    bool any_moved = false;
+#pragma unroll
+    for (int sl = 0; sl < NP; ++sl) {
+        m2[sl] = 0.f;
+        if (APPLY) {
+            const float ox = px[sl], oy = py[sl], oz = pz[sl];
+            // ((R0*x + R1*y) + R2*z) + T0 in fp64, no contraction, one rounding to fp32
+            double dx = (double)ox, dy = (double)oy, dz = (double)oz;
+            px[sl] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R0, dx), __dmul_rn(R1, dy)), __dmul_rn(R2, dz)), T0);
+            py[sl] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R3, dx), __dmul_rn(R4, dy)), __dmul_rn(R5, dz)), T1);
+            pz[sl] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R6, dx), __dmul_rn(R7, dy)), __dmul_rn(R8, dz)), T2);
+            const bool moved = px[sl] != ox || py[sl] != oy || pz[sl] != oz;
+            any_moved = any_moved || (live[sl] && moved);
+            float mx = px[sl] - ox, my = py[sl] - oy, mz = pz[sl] - oz;
+            m2[sl] = moved ? mx * mx + my * my + mz * mz : 0.f;
+            // in place the store can be skipped for a point that did not move
+            if (live[sl] && (moved || !in_place)) {
+                const long long i = tile0 + sl * kItThreads + (int)threadIdx.x;
+                sx_out[i] = px[sl]; sy_out[i] = py[sl]; sz_out[i] = pz[sl];
+            }
+        }
+    }
+
+    // ---- D: a tile none of whose points moves keeps its sums.  A point whose
+    // update rounds to the same three floats is where it was in the previous
+    // iteration, so its nearest neighbour, weight and row are the same bits; if
+    // that holds for the whole tile, its row of `partials` is still right and
+    // only the coordinates had to be read.  Near convergence most tiles are
+    // like that. ----
+    if (APPLY && CERTIFY && in_place) {
+        if (!__syncthreads_or(any_moved ? 1 : 0)) return;
     }
 
     double acc[30];
 #pragma unroll
     for (int v = 0; v < 30; ++v) acc[v] = 0.0;
 
-    // ---- pass 1 ----
-    unsigned queued_bits = 0;       // bit (h * kItPoints + p): that point needs a search
-    int my_rank[kItHalves * kItPoints];
-    float qx[kItHalves * kItPoints], qy[kItHalves * kItPoints], qz[kItHalves * kItPoints];
+    // ---- E/F: try to keep the previous correspondences ----
+    bool need_search[NP];
 #pragma unroll
-    for (int h = 0; h < kItHalves; ++h) {
-        float px[kItPoints], py[kItPoints], pz[kItPoints], lb[kItPoints];
-        float4 tp[kItPoints], nv[kItPoints];
-        bool live[kItPoints];
-        // all loads of the half tile are issued before anything waits on them
+    for (int sl = 0; sl < NP; ++sl) need_search[sl] = live[sl];
+    if (CERTIFY) {
+        // lb never exceeds cov, so a point that moved farther than that cannot
+        // be proven; when that is the whole wave the state is not even read
+        bool hopeless = true;
 #pragma unroll
-        for (int p = 0; p < kItPoints; ++p) {
-            const long long i = tile0 + (h * kItPoints + p) * kItThreads + (int)threadIdx.x;
-            live[p] = i < n;
-            const long long ic = live[p] ? i : 0;
-            px[p] = sx_in[ic]; py[p] = sy_in[ic]; pz[p] = sz_in[ic];
-            if (CERTIFY) { tp[p] = ps.tp[ic]; nv[p] = ps.nv[ic]; lb[p] = ps.lb[ic]; }
-        }
+        for (int sl = 0; sl < NP; ++sl) hopeless = hopeless && !(live[sl] && m2[sl] < cp.cov * cp.cov);
+        if (__ballot(!hopeless) != 0ull) {
+            float4 tp[NP], nv[NP];
+            float lb[NP];
 #pragma unroll
-        for (int p = 0; p < kItPoints; ++p) {
-            const long long i = tile0 + (h * kItPoints + p) * kItThreads + (int)threadIdx.x;
-            const float ox = px[p], oy = py[p], oz = pz[p];
-            if (APPLY) {
-                // ((R0*x + R1*y) + R2*z) + T0 in fp64, no contraction, one rounding to fp32
-                double dx = (double)ox, dy = (double)oy, dz = (double)oz;
-                px[p] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R0, dx), __dmul_rn(R1, dy)), __dmul_rn(R2, dz)), T0);
-                py[p] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R3, dx), __dmul_rn(R4, dy)), __dmul_rn(R5, dz)), T1);
-                pz[p] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R6, dx), __dmul_rn(R7, dy)), __dmul_rn(R8, dz)), T2);
-                // in place the store can be skipped for a point that did not move
-                const bool moved = px[p] != ox || py[p] != oy || pz[p] != oz;
-                if (live[p] && (moved || sx_in != sx_out)) {
-                    sx_out[i] = px[p]; sy_out[i] = py[p]; sz_out[i] = pz[p];
-                }
+            for (int sl = 0; sl < NP; ++sl) {
+                const long long i = tile0 + sl * kItThreads + (int)threadIdx.x;
+                const long long ic = live[sl] ? i : 0;
+                tp[sl] = ps.tp[ic]; nv[sl] = ps.nv[ic]; lb[sl] = ps.lb[ic];
             }
-            bool need_search = live[p];
-            if (CERTIFY) {
-                float mx = px[p] - ox, my = py[p] - oy, mz = pz[p] - oz;
-                float m2 = mx * mx + my * my + mz * mz;
-                float lbn = lb[p];
-                if (m2 > 0.f) lbn = (lbn - sqrtf(m2) * 1.00001f) * 0.99999f;
-                const int pos = __float_as_int(tp[p].w);
-                float dx = px[p] - tp[p].x, dy = py[p] - tp[p].y, dz = pz[p] - tp[p].z;
+#pragma unroll
+            for (int sl = 0; sl < NP; ++sl) {
+                const long long i = tile0 + sl * kItThreads + (int)threadIdx.x;
+                float lbn = lb[sl];
+                if (m2[sl] > 0.f) lbn = (lbn - sqrtf(m2[sl]) * 1.00001f) * 0.99999f;
+                const int pos = __float_as_int(tp[sl].w);
+                float dx = px[sl] - tp[sl].x, dy = py[sl] - tp[sl].y, dz = pz[sl] - tp[sl].z;
                 float d2 = __fmul_rn(dx, dx);
                 d2 = __fadd_rn(d2, __fmul_rn(dy, dy));
                 d2 = __fadd_rn(d2, __fmul_rn(dz, dz));
                 // sqrt(d2) * (1 + 1e-5) < lbn, compared as squares
-                const bool proven_nn = pos >= 0 && lbn > 0.f && d2 * 1.00003f < lbn * lbn;
-                const bool proven_none = pos < 0 && lbn > cp.root_hi;
-                need_search = live[p] && !(proven_nn || proven_none);
-                if (live[p] && !need_search && m2 > 0.f) ps.lb[i] = lbn;
-                if (live[p] && proven_nn && d2 <= cp.thr)
-                    accumulate_point(acc, px[p], py[p], pz[p], d2, cp.thr, tp[p].x, tp[p].y,
-                                     tp[p].z, nv[p].x, nv[p].y, nv[p].z);
+                // a point that did not move keeps what the last search or proof
+                // at this very position established, near-ties included
+                const bool still = m2[sl] == 0.f;
+                const bool proven_nn =
+                    pos >= 0 && (still || (lbn > 0.f && d2 * 1.00003f < lbn * lbn));
+                const bool proven_none = pos < 0 && (still || lbn > cp.root_hi);
+                need_search[sl] = live[sl] && !(proven_nn || proven_none);
+                if (live[sl] && !need_search[sl] && m2[sl] > 0.f) ps.lb[i] = lbn;
+                if (live[sl] && proven_nn && d2 <= cp.thr)
+                    accumulate_point(acc, px[sl], py[sl], pz[sl], d2, cp.thr, tp[sl].x, tp[sl].y,
+                                     tp[sl].z, nv[sl].x, nv[sl].y, nv[sl].z);
             }
-            // position of this point among the queued ones of its wave
-            const unsigned long long mask = __ballot(need_search);
-            const int slot = h * kItPoints + p;
-            my_rank[slot] = __popcll(mask & ((1ull << lane) - 1ull));
-            if (need_search) queued_bits |= 1u << slot;
-            if (lane == 0) wcount[slot][wv] = __popcll(mask);
-            qx[slot] = px[p]; qy[slot] = py[p]; qz[slot] = pz[p];
         }
     }
+
+    // ---- queue of the points that need a search, in a fixed order: by slot,
+    // then by thread (ballot + popcount per wave, wave totals through LDS) ----
+    int my_rank[NP];
+#pragma unroll
+    for (int sl = 0; sl < NP; ++sl) {
+        const unsigned long long mask = __ballot(need_search[sl]);
+        my_rank[sl] = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[sl][wv] = __popcll(mask);
+    }
     __syncthreads();
-    // fixed order of the queue: by pass, then by thread
     int total = 0;
 #pragma unroll
-    for (int slot = 0; slot < kItHalves * kItPoints; ++slot) {
+    for (int sl = 0; sl < NP; ++sl) {
         int before = 0, all = 0;
 #pragma unroll
         for (int w = 0; w < kItThreads / 64; ++w) {
-            const int c = wcount[slot][w];
+            const int c = wcount[sl][w];
             before += w < wv ? c : 0;
             all += c;
         }
-        if (queued_bits & (1u << slot))
-            queue[total + before + my_rank[slot]] = make_float4(
-                qx[slot], qy[slot], qz[slot], __int_as_float(slot * kItThreads + (int)threadIdx.x));
+        if (need_search[sl])
+            queue[total + before + my_rank[sl]] = make_float4(
+                px[sl], py[sl], pz[sl], __int_as_float(sl * kItThreads + (int)threadIdx.x));
         total += all;
     }
     __syncthreads();
 
-    // ---- pass 2: search the queued points ----
+    // ---- G: search the queued points (CPoint2PlaneICP.cpp:65-67) ----
     for (int q = threadIdx.x; q < total; q += kItThreads) {
         const float4 e = queue[q];
         const long long i = tile0 + __float_as_int(e.w);
@@ -690,37 +749,26 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
         ps.lb[i] = lbn;
     }
 
+    // ---- H: the tile's new sums replace its row; the difference goes to this
+    // iteration's delta (one fp64 atomic per changed sum) ----
     const double s = block_sum_30(acc, red);
-    if (threadIdx.x < kNumSums) partials[(size_t)threadIdx.x * nb + tile] = s;
-}
-
-// Sums one row of the tile partials (value-major [32][nb]) per block, in a
-// fixed order.
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restrict__ partials,
-                                                          int nb, double *__restrict__ sums)
-{
-    __shared__ double red[4];
-    const int v = blockIdx.x;
-    const double *row = partials + (size_t)v * nb;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = threadIdx.x;
-    for (; b + 768 < nb; b += 1024) {
-        s0 += row[b]; s1 += row[b + 256]; s2 += row[b + 512]; s3 += row[b + 768];
+    if (threadIdx.x < 30) {
+        partials[(size_t)threadIdx.x * nb + tile] = s;
+        const double d = s - old_row;
+        if (d != 0.0) atomicAdd(deltas + (size_t)iter * kNumSums + threadIdx.x, d);
     }
-    for (; b < nb; b += 256) s0 += row[b];
-    double s = wave_sum_lane63((s0 + s1) + (s2 + s3));
-    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) sums[v] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// One wave: solve from the 32 sums and record the result (the last iteration
-// of a run has no following iteration kernel to do it).
-__global__ __launch_bounds__(64) void solve_kernel(const double *__restrict__ sums, IcpState *st,
-                                                   double *X_hist, double *info_hist, int iter)
+// One wave: solve the system of iteration `iter` and record the result (the
+// last iteration of a run has no following iteration kernel to do it).
+__global__ __launch_bounds__(64) void solve_kernel(double *totals, const double *deltas,
+                                                   IcpState *st, double *X_hist,
+                                                   double *info_hist, int iter)
 {
     __shared__ double rt[12];
-    solve_and_update(sums, st, X_hist, info_hist, iter, true, rt);
+    solve_and_update(totals + (size_t)iter * kNumSums, deltas + (size_t)iter * kNumSums,
+                     totals + (size_t)(iter + 1) * kNumSums, st, X_hist, info_hist, iter, true,
+                     rt);
 }
 
 __global__ void reset_state_kernel(IcpState *st)
