@@ -1,0 +1,76 @@
+/*
+ * svcal.h - C ABI (in libsvicp.so) of the calibration reprojection path:
+ * residuals and the central-difference Jacobian of the reference's stereo and
+ * monocular bundle refinement, reduced on the device to the block-sparse normal
+ * equations an LM step needs.  Status codes are those of svicp.h.
+ *
+ * Replaces the evaluation lambdas inside
+ *   CStereoCameraCalibration::doStereoCalibrate
+ *       value    Calibration/CStereoCameraCalibration.cpp:25-50
+ *       residual Calibration/CStereoCameraCalibration.cpp:51-80
+ *       jacobian Calibration/CStereoCameraCalibration.cpp:81-247 (+ J^T J, J^T e of :274-276)
+ *   CMonocularCameraCalibration::refineAllPara
+ *       value2 / residual2 / jacobian2  Calibration/CMonocularCameraCalibration.cpp:737-906
+ * The reference forms the dense Jacobian (rows x (8 + 2k + 6V + 6)); here only its
+ * non-zero blocks are evaluated and J^T J is returned block by block.
+ *
+ * Parameter vector, as composeStereoPara lays it out
+ * (CStereoCameraCalibration.cpp:478-518), nI = 4 + k, k = 2 or 5:
+ *   [fxL fyL cxL cyL distL(k) | fxR fyR cxR cyR distR(k) | V x (rvecL, tL) | rvecS tS]
+ * Monocular (composeCameraPara with zero skew and five distortion terms,
+ * CMonocularCameraCalibration.cpp:1045-1082):
+ *   [fx fy cx cy dist(5) | V x (rvec, t)]
+ */
+#ifndef SVCAL_H
+#define SVCAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svcal_ctx svcal_ctx;
+
+/* Caller-provided output blocks (host memory, row-major, symmetric blocks
+ * full).  Any pointer may be NULL to skip that block.
+ *   LL nI x nI, RR nI x nI, RS nI x 6, SS 6 x 6   (R*, *S unused for monocular)
+ *   LE V x nI x 6, EE V x 6 x 6                    per view
+ *   gL nI, gR nI, gE V x 6, gS 6                   J^T e
+ *   residual: 4 V C (stereo: left rows then right rows, projected - observed,
+ *             CStereoCameraCalibration.cpp:59-78) or 2 V C (monocular: observed -
+ *             projected, CMonocularCameraCalibration.cpp:821-822)               */
+typedef struct svcal_blocks {
+    double *LL, *RR, *RS, *SS, *LE, *EE;
+    double *gL, *gR, *gE, *gS;
+    double *residual;
+    double sq_residual;     /* out: |e|^2 */
+} svcal_blocks;
+
+int svcal_create(int device_id, svcal_ctx **out);
+int svcal_destroy(svcal_ctx *ctx);
+const char *svcal_last_error(const svcal_ctx *ctx);
+
+/* The board and the detected corners: world_xy C x 2 (z = 0 as in the
+ * reference), left_xy / right_xy V x C x 2 pixels.  right_xy NULL: monocular. */
+int svcal_set_observations(svcal_ctx *ctx, const double *world_xy, int corners,
+                           const double *left_xy, const double *right_xy, int views);
+
+/* Uploads a parameter vector (length 2 nI + 6 V + 6, or 9 + 6 V monocular). */
+int svcal_set_params(svcal_ctx *ctx, const double *params, int k_size);
+
+/* Evaluates residuals and the block-sparse normal equations at the uploaded
+ * parameters, leaving the results on the device (what an iteration on the
+ * device, or a throughput measurement, needs). */
+int svcal_eval(svcal_ctx *ctx);
+
+/* Copies the results of the last svcal_eval into the caller's blocks. */
+int svcal_fetch(svcal_ctx *ctx, svcal_blocks *out);
+
+/* Average duration (ms) of `reps` back-to-back svcal_eval launches. */
+int svcal_time_eval(svcal_ctx *ctx, int reps, double *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVCAL_H */

@@ -15,9 +15,9 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "icp_oracle.c")
-    if force or not os.path.exists(so) or (
-        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)
+    srcs = [os.path.join(_HERE, f) for f in ("icp_oracle.c", "cal_oracle.c")]
+    if force or not os.path.exists(so) or any(
+        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so) for src in srcs
     ):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
     return so
@@ -149,3 +149,73 @@ def parse_txt(text: bytes):
 
 def max_threads():
     return lib().orc_max_threads()
+
+
+# ---------------------------------------------------------------- calibration
+def _cal_lib():
+    L = lib()
+    if not getattr(L, "_cal_bound", False):
+        dp = C.POINTER(C.c_double)
+        L.orc_rodrigues.argtypes = [dp, dp]
+        L.orc_cal_value.argtypes = [dp, dp, C.c_int, dp, C.c_double, C.c_double, dp]
+        L.orc_stereo_residual.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp]
+        L.orc_stereo_jacobian_dense.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, dp]
+        L.orc_stereo_eval_sparse.restype = C.c_double
+        L.orc_stereo_eval_sparse.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, dp, dp] + [dp] * 11
+        L.orc_mono_residual_jacobian_dense.argtypes = [dp, C.c_int, C.c_int, dp, dp, dp, dp]
+        L._cal_bound = True
+    return L
+
+
+def _dd(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def rodrigues(r):
+    r = _dd(r).reshape(3)
+    R = np.empty(9)
+    _cal_lib().orc_rodrigues(_d(r), _d(R))
+    return R.reshape(3, 3)
+
+
+def stereo_residual(vec, k, world, left, right):
+    vec, world, left, right = _dd(vec), _dd(world), _dd(left), _dd(right)
+    V, Cn = left.shape[0], left.shape[1]
+    res = np.empty(4 * V * Cn)
+    _cal_lib().orc_stereo_residual(_d(vec), k, V, Cn, _d(world), _d(left), _d(right), _d(res))
+    return res
+
+
+def stereo_jacobian_dense(vec, k, world, V):
+    vec, world = _dd(vec), _dd(world)
+    Cn = world.shape[0]
+    J = np.empty((4 * V * Cn, len(vec)))
+    _cal_lib().orc_stereo_jacobian_dense(_d(vec), k, V, Cn, _d(world), _d(J))
+    return J
+
+
+def stereo_eval_sparse(vec, k, world, left, right, want_residual=True):
+    vec, world, left, right = _dd(vec), _dd(world), _dd(left), _dd(right)
+    V, Cn = left.shape[0], left.shape[1]
+    nI = 4 + k
+    out = dict(LL=np.empty((nI, nI)), RR=np.empty((nI, nI)), RS=np.empty((nI, 6)),
+               SS=np.empty((6, 6)), LE=np.empty((V, nI, 6)), EE=np.empty((V, 6, 6)),
+               gL=np.empty(nI), gR=np.empty(nI), gE=np.empty((V, 6)), gS=np.empty(6))
+    res = np.empty(4 * V * Cn) if want_residual else None
+    ss = _cal_lib().orc_stereo_eval_sparse(
+        _d(vec), k, V, Cn, _d(world), _d(left), _d(right),
+        *[_d(out[n]) for n in ("LL", "RR", "RS", "SS", "LE", "EE", "gL", "gR", "gE", "gS")],
+        _d(res) if want_residual else None)
+    out["residual"] = res
+    out["sq_residual"] = ss
+    return out
+
+
+def mono_residual_jacobian_dense(vec, world, img, want_jacobian=True):
+    vec, world, img = _dd(vec), _dd(world), _dd(img)
+    V, Cn = img.shape[0], img.shape[1]
+    res = np.empty(2 * V * Cn)
+    J = np.empty((2 * V * Cn, len(vec))) if want_jacobian else None
+    _cal_lib().orc_mono_residual_jacobian_dense(_d(vec), V, Cn, _d(world), _d(img), _d(res),
+                                                _d(J) if want_jacobian else None)
+    return res, J

@@ -1,0 +1,192 @@
+"""Reprojection residual / Jacobian evaluation of the calibration refinement on the GPU.
+
+`ReprojectionEvaluator` wraps one svcal_ctx (include/svcal.h).  It evaluates
+what the lambdas inside CStereoCameraCalibration::doStereoCalibrate
+(Calibration/CStereoCameraCalibration.cpp:25-247) and
+CMonocularCameraCalibration::refineAllPara
+(Calibration/CMonocularCameraCalibration.cpp:737-906) evaluate, and returns
+J^T J and J^T e block by block instead of the reference's dense Jacobian.
+`assemble_dense` and `lm_refine` are host-side helpers for small problems: the
+reference's Levenberg-Marquardt loop (CStereoCameraCalibration.cpp:278-335) on
+top of the device evaluation.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SvicpError
+
+_dp = C.POINTER(C.c_double)
+
+
+class _Blocks(C.Structure):
+    _fields_ = [(n, _dp) for n in ("LL", "RR", "RS", "SS", "LE", "EE", "gL", "gR", "gE", "gS",
+                                   "residual")] + [("sq_residual", C.c_double)]
+
+
+CAL_SYMBOLS = {
+    "svcal_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "svcal_destroy": (C.c_int, [C.c_void_p]),
+    "svcal_last_error": (C.c_char_p, [C.c_void_p]),
+    "svcal_set_observations": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp, C.c_int]),
+    "svcal_set_params": (C.c_int, [C.c_void_p, _dp, C.c_int]),
+    "svcal_eval": (C.c_int, [C.c_void_p]),
+    "svcal_fetch": (C.c_int, [C.c_void_p, C.POINTER(_Blocks)]),
+    "svcal_time_eval": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+}
+
+
+def _load():
+    lib = _lib.load()
+    if not getattr(lib, "_cal_bound", False):
+        for name, (res, args) in CAL_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        lib._cal_bound = True
+    return lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+class ReprojectionEvaluator:
+    def __init__(self, world_xy, left_xy, right_xy=None, device=0):
+        self._lib = _load()
+        self._h = C.c_void_p()
+        rc = self._lib.svcal_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise SvicpError(rc, self._lib.svcal_last_error(None).decode())
+        self.world = np.ascontiguousarray(world_xy, np.float64)
+        self.left = np.ascontiguousarray(left_xy, np.float64)
+        self.right = None if right_xy is None else np.ascontiguousarray(right_xy, np.float64)
+        self.V, self.C = self.left.shape[0], self.left.shape[1]
+        assert self.world.shape == (self.C, 2) and self.left.shape == (self.V, self.C, 2)
+        assert self.right is None or self.right.shape == self.left.shape
+        self._check(self._lib.svcal_set_observations(
+            self._h, _d(self.world), self.C, _d(self.left),
+            _d(self.right) if self.right is not None else None, self.V))
+        self.k = 5
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SvicpError(rc, self._lib.svcal_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.svcal_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stereo(self):
+        return self.right is not None
+
+    def n_params(self, k=5):
+        nI = 4 + k
+        return 2 * nI + 6 * self.V + 6 if self.stereo else nI + 6 * self.V
+
+    def set_params(self, params, k=5):
+        p = np.ascontiguousarray(params, np.float64)
+        if p.shape != (self.n_params(k),):
+            raise ValueError(f"expected {self.n_params(k)} parameters, got {p.shape}")
+        self.k = k
+        self._check(self._lib.svcal_set_params(self._h, _d(p), k))
+
+    def eval(self):
+        """Launches the evaluation; results stay on the device until fetch()."""
+        self._check(self._lib.svcal_eval(self._h))
+
+    def fetch(self, want_residual=True):
+        nI, V = 4 + self.k, self.V
+        out = dict(LL=np.zeros((nI, nI)), gL=np.zeros(nI), LE=np.zeros((V, nI, 6)),
+                   EE=np.zeros((V, 6, 6)), gE=np.zeros((V, 6)))
+        if self.stereo:
+            out.update(RR=np.zeros((nI, nI)), RS=np.zeros((nI, 6)), SS=np.zeros((6, 6)),
+                       gR=np.zeros(nI), gS=np.zeros(6))
+        if want_residual:
+            out["residual"] = np.zeros(2 * V * self.C * (2 if self.stereo else 1))
+        b = _Blocks()
+        for name, arr in out.items():
+            setattr(b, name, _d(arr))
+        self._check(self._lib.svcal_fetch(self._h, C.byref(b)))
+        out["sq_residual"] = b.sq_residual
+        return out
+
+    def evaluate(self, params, k=5, want_residual=True):
+        self.set_params(params, k)
+        self.eval()
+        return self.fetch(want_residual)
+
+    def time_eval(self, reps=20):
+        ms = C.c_double()
+        self._check(self._lib.svcal_time_eval(self._h, int(reps), C.byref(ms)))
+        return ms.value
+
+
+def assemble_dense(blocks, k, V, stereo=True):
+    """Dense A = J^T J and G = J^T e in the reference's column order (small V only)."""
+    nI = 4 + k
+    if stereo:
+        P = 2 * nI + 6 * V + 6
+        A, G = np.zeros((P, P)), np.zeros(P)
+        A[:nI, :nI] = blocks["LL"]
+        A[nI:2 * nI, nI:2 * nI] = blocks["RR"]
+        s0 = 2 * nI + 6 * V
+        A[nI:2 * nI, s0:] = blocks["RS"]
+        A[s0:, nI:2 * nI] = blocks["RS"].T
+        A[s0:, s0:] = blocks["SS"]
+        G[:nI], G[nI:2 * nI], G[s0:] = blocks["gL"], blocks["gR"], blocks["gS"]
+        e0 = 2 * nI
+    else:
+        P = nI + 6 * V
+        A, G = np.zeros((P, P)), np.zeros(P)
+        A[:nI, :nI] = blocks["LL"]
+        G[:nI] = blocks["gL"]
+        e0 = nI
+    for v in range(V):
+        c = e0 + 6 * v
+        A[:nI, c:c + 6] = blocks["LE"][v]
+        A[c:c + 6, :nI] = blocks["LE"][v].T
+        A[c:c + 6, c:c + 6] = blocks["EE"][v]
+        G[c:c + 6] = blocks["gE"][v]
+    return A, G
+
+
+def lm_refine(evaluator, params, k=5, max_iter=100, verbose=False):
+    """The reference's damped Gauss-Newton loop (CStereoCameraCalibration.cpp:278-335):
+    lambda0 = 1e-3, A + lambda diag(A), gain-ratio update, stops on |step| < 1e-5,
+    |e| < 1e-3 or 100 iterations.  Dense solve on the host: for small V."""
+    x = np.array(params, np.float64)
+    V, stereo = evaluator.V, evaluator.stereo
+    b = evaluator.evaluate(x, k, want_residual=False)
+    A, G = assemble_dense(b, k, V, stereo)
+    err2 = b["sq_residual"]
+    lam, v = 1.0e-3, 2.0
+    for it in range(max_iter):
+        step = -np.linalg.solve(A + lam * np.diag(np.diag(A)), G)
+        if np.linalg.norm(step) < 1.0e-5:
+            break
+        nb = evaluator.evaluate(x + step, k, want_residual=False)
+        r = (err2 - nb["sq_residual"]) / float(step @ (lam * step - G))
+        if verbose:
+            print(f"iter {it}: |e| {np.sqrt(err2):.6g} -> {np.sqrt(nb['sq_residual']):.6g}, gain {r:.3g}")
+        if r > 0:
+            x = x + step
+            A, G = assemble_dense(nb, k, V, stereo)
+            err2 = nb["sq_residual"]
+            if np.sqrt(err2) < 1.0e-3:
+                break
+            lam *= max(1.0 / 3.0, 1.0 - (2.0 * r - 1.0) ** 3)
+            v = 2.0
+        else:
+            lam *= v
+            v *= 2.0
+    return x, np.sqrt(err2)

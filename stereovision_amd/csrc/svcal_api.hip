@@ -1,0 +1,240 @@
+// Host side of the calibration reprojection path: the C ABI of include/svcal.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "svcal.h"
+#include "svcal_device.hpp"
+#include "svicp.h"
+
+using namespace svcal;
+
+struct svcal_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int V = 0, C = 0, k = 5, stereo = 0;
+    bool have_obs = false, have_params = false, evaluated = false;
+    double *world = nullptr, *left = nullptr, *right = nullptr, *params = nullptr;
+    double *gram_view = nullptr, *gram_sum = nullptr, *residual = nullptr;
+    size_t cap_params = 0;
+};
+
+namespace {
+thread_local std::string g_cal_create_error;
+
+int cfail(svcal_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    if (c) c->err = buf; else g_cal_create_error = buf;
+    return code;
+}
+#define CHK(call)                                                            \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, #call, e_);   \
+    } while (0)
+
+void free_obs(svcal_ctx *ctx)
+{
+    void *bufs[] = { ctx->world, ctx->left, ctx->right, ctx->gram_view, ctx->gram_sum, ctx->residual };
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    ctx->world = ctx->left = ctx->right = ctx->gram_view = ctx->gram_sum = ctx->residual = nullptr;
+}
+
+int param_count(const svcal_ctx *ctx, int k)
+{
+    const int nI = 4 + k;
+    return ctx->stereo ? 2 * nI + 6 * ctx->V + 6 : nI + 6 * ctx->V;
+}
+}  // namespace
+
+extern "C" {
+
+const char *svcal_last_error(const svcal_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_cal_create_error.c_str();
+}
+
+int svcal_create(int device_id, svcal_ctx **out)
+{
+    svcal_ctx *ctx = nullptr;
+    if (!out) return cfail(nullptr, SVICP_ERR_ARG, "svcal_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return cfail(nullptr, SVICP_ERR_NO_DEVICE, "svcal_create: no HIP device is visible");
+    if (device_id < 0 || device_id >= count)
+        return cfail(nullptr, SVICP_ERR_ARG, "svcal_create: device_id out of range");
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess)
+        return cfail(nullptr, SVICP_ERR_HIP, "svcal_create: cannot query the device");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return cfail(nullptr, SVICP_ERR_NO_DEVICE, "svcal_create: the library holds gfx950 code only");
+    ctx = new svcal_ctx();
+    ctx->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return cfail(nullptr, SVICP_ERR_HIP, "hipStreamCreate", e); }
+    *out = ctx;
+    return SVICP_OK;
+}
+
+int svcal_destroy(svcal_ctx *ctx)
+{
+    if (!ctx) return SVICP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_obs(ctx);
+    if (ctx->params) (void)hipFree(ctx->params);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SVICP_OK;
+}
+
+int svcal_set_observations(svcal_ctx *ctx, const double *world_xy, int corners,
+                           const double *left_xy, const double *right_xy, int views)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (!world_xy || !left_xy || corners < 1 || views < 1)
+        return cfail(ctx, SVICP_ERR_ARG, "svcal_set_observations: bad argument");
+    CHK(hipSetDevice(ctx->device));
+    CHK(hipStreamSynchronize(ctx->stream));
+    free_obs(ctx);
+    ctx->have_obs = ctx->have_params = ctx->evaluated = false;
+    ctx->V = views; ctx->C = corners; ctx->stereo = right_xy ? 1 : 0;
+    const size_t nobs = sizeof(double) * 2 * (size_t)views * corners;
+    CHK(hipMalloc((void **)&ctx->world, sizeof(double) * 2 * corners));
+    CHK(hipMalloc((void **)&ctx->left, nobs));
+    CHK(hipMalloc((void **)&ctx->gram_view, sizeof(double) * 2 * kGram * (size_t)views));
+    CHK(hipMalloc((void **)&ctx->gram_sum, sizeof(double) * 2 * kGram));
+    CHK(hipMalloc((void **)&ctx->residual, nobs * (ctx->stereo ? 2 : 1)));
+    CHK(hipMemcpyAsync(ctx->world, world_xy, sizeof(double) * 2 * corners, hipMemcpyHostToDevice, ctx->stream));
+    CHK(hipMemcpyAsync(ctx->left, left_xy, nobs, hipMemcpyHostToDevice, ctx->stream));
+    if (right_xy) {
+        CHK(hipMalloc((void **)&ctx->right, nobs));
+        CHK(hipMemcpyAsync(ctx->right, right_xy, nobs, hipMemcpyHostToDevice, ctx->stream));
+    }
+    CHK(hipMemsetAsync(ctx->gram_view, 0, sizeof(double) * 2 * kGram * (size_t)views, ctx->stream));
+    CHK(hipMemsetAsync(ctx->gram_sum, 0, sizeof(double) * 2 * kGram, ctx->stream));
+    CHK(hipStreamSynchronize(ctx->stream));
+    ctx->have_obs = true;
+    return SVICP_OK;
+}
+
+int svcal_set_params(svcal_ctx *ctx, const double *params, int k_size)
+{
+    if (!ctx || !params) return cfail(ctx, SVICP_ERR_ARG, "svcal_set_params: NULL argument");
+    if (!ctx->have_obs) return cfail(ctx, SVICP_ERR_ARG, "svcal_set_params: set the observations first");
+    if (k_size != 2 && k_size != 5)
+        return cfail(ctx, SVICP_ERR_ARG, "svcal_set_params: k_size must be 2 or 5");
+    if (!ctx->stereo && k_size != 5)
+        return cfail(ctx, SVICP_ERR_ARG, "svcal_set_params: the monocular path has five distortion terms");
+    CHK(hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(double) * (size_t)param_count(ctx, k_size);
+    if (bytes > ctx->cap_params) {
+        if (ctx->params) CHK(hipFree(ctx->params));
+        ctx->params = nullptr; ctx->cap_params = 0;
+        CHK(hipMalloc((void **)&ctx->params, bytes));
+        ctx->cap_params = bytes;
+    }
+    ctx->k = k_size;
+    CHK(hipMemcpyAsync(ctx->params, params, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CHK(hipStreamSynchronize(ctx->stream));   // the caller may reuse its buffer
+    ctx->have_params = true;
+    return SVICP_OK;
+}
+
+int svcal_eval(svcal_ctx *ctx)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (!ctx->have_params) return cfail(ctx, SVICP_ERR_ARG, "svcal_eval: set the parameters first");
+    CHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(cal_eval_kernel, dim3(ctx->V), dim3(kThreads), 0, ctx->stream, ctx->params,
+                       ctx->k, ctx->V, ctx->C, ctx->stereo, ctx->world, ctx->left, ctx->right,
+                       ctx->gram_view, ctx->residual);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "cal_eval_kernel", e);
+    hipLaunchKernelGGL(cal_reduce_kernel, dim3((ctx->stereo ? 2 : 1) * kGram), dim3(256), 0,
+                       ctx->stream, ctx->gram_view, ctx->V, ctx->gram_sum);
+    e = hipGetLastError();
+    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "cal_reduce_kernel", e);
+    ctx->evaluated = true;
+    return SVICP_OK;
+}
+
+int svcal_fetch(svcal_ctx *ctx, svcal_blocks *out)
+{
+    if (!ctx || !out) return cfail(ctx, SVICP_ERR_ARG, "svcal_fetch: NULL argument");
+    if (!ctx->evaluated) return cfail(ctx, SVICP_ERR_ARG, "svcal_fetch: nothing evaluated yet");
+    CHK(hipSetDevice(ctx->device));
+    const int V = ctx->V, nI = 4 + ctx->k;
+    std::vector<double> gv(2 * kGram * (size_t)V), gs(2 * kGram);
+    CHK(hipMemcpyAsync(gv.data(), ctx->gram_view, sizeof(double) * gv.size(), hipMemcpyDeviceToHost, ctx->stream));
+    CHK(hipMemcpyAsync(gs.data(), ctx->gram_sum, sizeof(double) * gs.size(), hipMemcpyDeviceToHost, ctx->stream));
+    if (out->residual)
+        CHK(hipMemcpyAsync(out->residual, ctx->residual,
+                           sizeof(double) * 2 * (size_t)V * ctx->C * (ctx->stereo ? 2 : 1),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    CHK(hipStreamSynchronize(ctx->stream));
+    // entry (a, b), a <= b, of a 16 x 16 upper triangle stored row by row
+    auto at = [](int a, int b) { if (a > b) std::swap(a, b); return a * 16 - (a * (a - 1)) / 2 + (b - a); };
+    const double *GL = gs.data(), *GR = gs.data() + kGram;
+    for (int a = 0; a < nI; ++a) {
+        for (int b = 0; b < nI; ++b) {
+            if (out->LL) out->LL[a * nI + b] = GL[at(a, b)];
+            if (out->RR && ctx->stereo) out->RR[a * nI + b] = GR[at(a, b)];
+        }
+        if (out->gL) out->gL[a] = GL[at(a, 15)];
+        if (ctx->stereo) {
+            if (out->gR) out->gR[a] = GR[at(a, 15)];
+            if (out->RS) for (int q = 0; q < 6; ++q) out->RS[a * 6 + q] = GR[at(a, nI + q)];
+        }
+    }
+    if (ctx->stereo)
+        for (int q = 0; q < 6; ++q) {
+            if (out->gS) out->gS[q] = GR[at(nI + q, 15)];
+            if (out->SS) for (int p = 0; p < 6; ++p) out->SS[q * 6 + p] = GR[at(nI + q, nI + p)];
+        }
+    for (int v = 0; v < V; ++v) {
+        const double *G = gv.data() + (size_t)v * 2 * kGram;
+        for (int q = 0; q < 6; ++q) {
+            if (out->gE) out->gE[(size_t)v * 6 + q] = G[at(nI + q, 15)];
+            if (out->EE) for (int p = 0; p < 6; ++p) out->EE[((size_t)v * 6 + q) * 6 + p] = G[at(nI + q, nI + p)];
+            if (out->LE) for (int a = 0; a < nI; ++a) out->LE[((size_t)v * nI + a) * 6 + q] = G[at(a, nI + q)];
+        }
+    }
+    out->sq_residual = GL[at(15, 15)] + (ctx->stereo ? GR[at(15, 15)] : 0.0);
+    return SVICP_OK;
+}
+
+int svcal_time_eval(svcal_ctx *ctx, int reps, double *avg_ms)
+{
+    if (!ctx || !avg_ms || reps < 1) return cfail(ctx, SVICP_ERR_ARG, "svcal_time_eval: bad argument");
+    int rc = svcal_eval(ctx);   // warm-up
+    if (rc) return rc;
+    hipEvent_t a, b;
+    CHK(hipEventCreate(&a));
+    CHK(hipEventCreate(&b));
+    CHK(hipEventRecord(a, ctx->stream));
+    for (int r = 0; r < reps; ++r) {
+        rc = svcal_eval(ctx);
+        if (rc) return rc;
+    }
+    CHK(hipEventRecord(b, ctx->stream));
+    CHK(hipEventSynchronize(b));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *avg_ms = (double)ms / reps;
+    return SVICP_OK;
+}
+
+}  // extern "C"

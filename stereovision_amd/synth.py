@@ -96,3 +96,62 @@ def make_pair(side, pair=0, pose=None):
     P[:3, :3] = R
     P[:3, 3] = c + t - R @ c
     return tgt.astype(np.float32), nrm.astype(np.float32), src.astype(np.float32), P
+
+
+SEED_CALIB = 0x5EED0005
+
+
+def rodrigues(r):
+    """Rotation vector -> matrix, I + sin(t) K + (1 - cos(t)) K^2."""
+    r = np.asarray(r, np.float64)
+    t = np.linalg.norm(r)
+    if t < 1e-6:
+        return np.eye(3)
+    a = r / t
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(t) * K + (1 - np.cos(t)) * (K @ K)
+
+
+def project(intr, dist, E, world_xy):
+    """The reference's five-term projection model (r = nx^2 + ny^2)."""
+    p = np.concatenate([world_xy, np.zeros((len(world_xy), 1)), np.ones((len(world_xy), 1))], axis=1)
+    c = p @ E.T
+    nx, ny = c[:, 0] / c[:, 2], c[:, 1] / c[:, 2]
+    r = nx * nx + ny * ny
+    k1, k2, p1, p2, k3 = dist
+    rad = 1.0 + k1 * r + k2 * r * r + k3 * r * r * r
+    xe = nx * rad + 2.0 * p1 * nx * ny + p2 * (r * r + 2.0 * nx * nx)
+    ye = ny * rad + p1 * (r * r + 2.0 * ny * ny) + 2.0 * p2 * nx * ny
+    return np.stack([intr[0] * xe + intr[2], intr[1] * ye + intr[3]], axis=1)
+
+
+def make_stereo_views(views=2000, board=(11, 8), square=25.0, noise=0.2, perturb=1e-3):
+    """Synthetic stereo calibration problem: an 11 x 8 board at 25 mm seen in `views`
+    poses by two cameras.  Returns (world (C,2), left (V,C,2), right (V,C,2),
+    true parameter vector, perturbed start vector) in the stereo layout with five
+    distortion terms: [intrL(4) distL(5) | intrR(4) distR(5) | V x (rvec, t) | rvecS tS]."""
+    bx, by = board
+    gx, gy = np.meshgrid(np.arange(bx) * square, np.arange(by) * square)
+    world = np.stack([gx.ravel(), gy.ravel()], axis=1).astype(np.float64)
+    C = len(world)
+    u = uniform01(SEED_CALIB, 0, 6 * views).reshape(views, 6)
+    rvec = (u[:, :3] - 0.5) * 0.7
+    t = np.stack([-120 + 100 * u[:, 3], -100 + 100 * u[:, 4], 450 + 450 * u[:, 5]], axis=1)
+    intr = np.array([535.0, 535.0, 320.0, 240.0])
+    dist = np.array([-0.28, 0.09, 1e-3, -5e-4, 0.0])
+    pose = np.array([0.01, -0.02, 0.005, -90.0, 1.0, 2.0])
+    S = np.concatenate([rodrigues(pose[:3]), pose[3:, None]], axis=1)
+    g1 = uniform01(SEED_CALIB, 6 * views, 4 * views * C).reshape(2, views, C, 2)
+    g2 = uniform01(SEED_CALIB, 6 * views + 4 * views * C, 4 * views * C).reshape(2, views, C, 2)
+    gauss = np.sqrt(-2.0 * np.log(1.0 - g1)) * np.cos(2.0 * np.pi * g2)
+    left = np.empty((views, C, 2))
+    right = np.empty((views, C, 2))
+    for v in range(views):
+        E = np.concatenate([rodrigues(rvec[v]), t[v][:, None]], axis=1)
+        Er = S @ np.concatenate([E, [[0, 0, 0, 1]]], axis=0)
+        left[v] = project(intr, dist, E, world) + noise * gauss[0, v]
+        right[v] = project(intr, dist, Er, world) + noise * gauss[1, v]
+    truth = np.concatenate([intr, dist, intr, dist, np.concatenate([rvec, t], axis=1).ravel(), pose])
+    w = uniform01(SEED_CALIB + 1, 0, len(truth)) - 0.5
+    start = truth * (1.0 + perturb * w) + perturb * w
+    return world, left, right, truth, start

@@ -86,3 +86,79 @@ def rot_angle(Ra, Rb):
     """Angle of Ra^T Rb in radians."""
     c = (np.trace(Ra.T @ Rb) - 1.0) / 2.0
     return float(np.arccos(np.clip(c, -1.0, 1.0)))
+
+
+def _homography(world, img):
+    """DLT homography world (C,2) -> img (C,2), normalised coordinates."""
+    def norm(p):
+        c = p.mean(0)
+        s = np.sqrt(2.0) / np.sqrt(((p - c) ** 2).sum(1)).mean()
+        T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1]])
+        return (p - c) * s, T
+    w, Tw = norm(world)
+    m, Tm = norm(img)
+    rows = []
+    for (X, Y), (u, v) in zip(w, m):
+        rows.append([X, Y, 1, 0, 0, 0, -u * X, -u * Y, -u])
+        rows.append([0, 0, 0, X, Y, 1, -v * X, -v * Y, -v])
+    _, _, vt = np.linalg.svd(np.asarray(rows))
+    H = np.linalg.inv(Tm) @ vt[-1].reshape(3, 3) @ Tw
+    return H / H[2, 2]
+
+
+def rotvec(R):
+    """Rotation matrix -> rotation vector."""
+    from scipy.spatial.transform import Rotation
+    U, _, Vt = np.linalg.svd(R)
+    R = U @ Vt
+    if np.linalg.det(R) < 0:
+        R = -R
+    return Rotation.from_matrix(R).as_rotvec()
+
+
+def homography_start(world, img, size, focal=None):
+    """A starting vector [fx fy cx cy 0 0 0 0 0 | V x (rvec, t)] for a planar board: the
+    principal point at the image centre, one focal length from the orthogonality constraint
+    of the homographies' first two columns, extrinsics from K^-1 H."""
+    cx, cy = size[0] / 2.0, size[1] / 2.0
+    Hs = [_homography(world, im) for im in img]
+    if focal is None:
+        est = []
+        for H in Hs:
+            Hc = np.array([[1, 0, -cx], [0, 1, -cy], [0, 0, 1.0]]) @ H
+            h1, h2 = Hc[:, 0], Hc[:, 1]
+            for num, den in ((-(h1[0] * h2[0] + h1[1] * h2[1]), h1[2] * h2[2]),
+                             (-(h1[0] ** 2 + h1[1] ** 2 - h2[0] ** 2 - h2[1] ** 2),
+                              h1[2] ** 2 - h2[2] ** 2)):
+                if abs(den) > 1e-12 and num / den > 0:
+                    est.append(np.sqrt(num / den))
+        focal = float(np.median(est))
+    K = np.array([[focal, 0, cx], [0, focal, cy], [0, 0, 1.0]])
+    out = [focal, focal, cx, cy, 0, 0, 0, 0, 0]
+    for H in Hs:
+        M = np.linalg.inv(K) @ H
+        lam = 2.0 / (np.linalg.norm(M[:, 0]) + np.linalg.norm(M[:, 1]))
+        if M[2, 2] * lam < 0:
+            lam = -lam
+        r1, r2, t = M[:, 0] * lam, M[:, 1] * lam, M[:, 2] * lam
+        R = np.stack([r1, r2, np.cross(r1, r2)], axis=1)
+        out += list(rotvec(R)) + list(t)
+    return np.asarray(out, np.float64)
+
+
+def stereo_start(world, left, right, size, focal=None):
+    """[intrL distL | intrR distR | V x left (rvec, t) | pose] from two monocular starts;
+    the pose is the median over views of right extrinsic * inverse(left extrinsic)."""
+    from scipy.spatial.transform import Rotation
+    a = homography_start(world, left, size, focal)
+    b = homography_start(world, right, size, focal)
+    V = len(left)
+    rv, tv = [], []
+    for v in range(V):
+        Rl = Rotation.from_rotvec(a[9 + 6 * v:12 + 6 * v]).as_matrix()
+        Rr = Rotation.from_rotvec(b[9 + 6 * v:12 + 6 * v]).as_matrix()
+        Rs = Rr @ Rl.T
+        rv.append(rotvec(Rs))
+        tv.append(b[12 + 6 * v:15 + 6 * v] - Rs @ a[12 + 6 * v:15 + 6 * v])
+    pose = np.r_[np.median(rv, axis=0), np.median(tv, axis=0)]
+    return np.r_[a[:9], b[:9], a[9:], pose]

@@ -10,10 +10,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    text = open(os.path.join(ROOT, "include", "svicp.h")).read()
+def _header_symbols(header="svicp.h", prefix="svicp_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(svicp_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -24,6 +24,28 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in svicp.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared, "ctypes table and header disagree"
+
+
+def test_calibration_symbols_are_exported():
+    from stereovision_amd import _lib, calib
+    lib = _lib.load()
+    declared = _header_symbols("svcal.h", "svcal_")
+    assert len(declared) == 8
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in svcal.h but not exported"
+    assert sorted(calib.CAL_SYMBOLS) == declared
+    assert ctypes.sizeof(calib._Blocks) == 12 * 8
+
+
+def test_calibration_needs_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    import stereovision_amd as sv
+    from stereovision_amd import calib
+    with pytest.raises(sv.SvicpError) as e:
+        calib.ReprojectionEvaluator(np.zeros((4, 2)), np.zeros((1, 4, 2)))
+    assert e.value.status == sv._lib.ERR_NO_DEVICE
 
 
 def test_struct_layouts_match_header():

@@ -1,0 +1,113 @@
+"""CPU checks of the calibration oracle (oracle/cal_oracle.c).
+
+The reference holds no expected outputs for its calibration (Test/demo.cpp only prints), so
+the oracle is pinned by independent restatements here: scipy for Rodrigues, a numpy projection,
+dense-versus-block-sparse agreement, and the reference's own corner tables as inputs.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from stereovision_amd import synth
+from stereovision_amd.calib import assemble_dense
+from tests.refmath import homography_start
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def corners():
+    return np.load(os.path.join(GOLD, "testdata_corners.npz"))
+
+
+def test_rodrigues_matches_scipy(po):
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        r = rng.normal(size=3) * rng.uniform(0.01, 2.5)
+        assert np.allclose(po.rodrigues(r), Rotation.from_rotvec(r).as_matrix(), atol=1e-13)
+    # below the reference's 1e-6 cut the matrix is the identity (Common/Misc.hpp:19-22)
+    assert np.array_equal(po.rodrigues([3e-7, 0, 0]), np.eye(3))
+
+
+def test_projection_matches_numpy(po):
+    w, l, r, truth, _ = synth.make_stereo_views(views=5, noise=0.0)
+    res = po.stereo_residual(truth, 5, w, l, r)
+    assert np.abs(res).max() < 1e-9
+    # the reference's model uses r = nx^2 + ny^2 where the textbook model has r^2, and r^2
+    # inside the tangential terms: a non-zero p2 therefore changes u even at nx = 0
+    E = np.hstack([np.eye(3), [[0], [0], [1.0]]])
+    p = synth.project([1, 1, 0, 0], [0, 0, 0, 1.0, 0], E, np.array([[0.0, 0.5]]))
+    assert np.allclose(p, [[0.25 ** 2, 0.5]])
+
+
+def test_sparse_blocks_equal_dense_normal_equations(po):
+    for k in (5, 2):
+        V = 4
+        w, l, r, truth, start = synth.make_stereo_views(views=V)
+        if k == 2:
+            nI = 9
+            keep = np.r_[0:6, nI:nI + 6, 2 * nI:len(start)]
+            start = start[keep]
+        J = po.stereo_jacobian_dense(start, k, w, V)
+        e = po.stereo_residual(start, k, w, l, r)
+        sp = po.stereo_eval_sparse(start, k, w, l, r)
+        A, G = assemble_dense(sp, k, V)
+        assert np.abs(A - J.T @ J).max() <= 1e-13 * np.abs(A).max()
+        assert np.abs(G - J.T @ e).max() <= 1e-13 * np.abs(G).max()
+        assert np.array_equal(sp["residual"], e)
+        assert sp["sq_residual"] == pytest.approx(e @ e, rel=1e-14)
+
+
+def test_left_extrinsic_columns_only_fill_left_rows(po):
+    """CStereoCameraCalibration.cpp:160-202 differentiates only the left image with respect
+    to a view's left extrinsics; the right rows of those columns stay zero."""
+    V = 3
+    w, l, r, _, start = synth.make_stereo_views(views=V)
+    J = po.stereo_jacobian_dense(start, 5, w, V)
+    C = len(w)
+    right_rows = J[2 * V * C:]
+    assert np.all(right_rows[:, 18:18 + 6 * V] == 0.0)
+    assert np.all(right_rows[:, :9] == 0.0)
+    assert np.any(right_rows[:, 9:18] != 0.0) and np.any(right_rows[:, 18 + 6 * V:] != 0.0)
+    left_rows = J[:2 * V * C]
+    assert np.all(left_rows[:, 9:18] == 0.0) and np.all(left_rows[:, 18 + 6 * V:] == 0.0)
+    for v in range(V):
+        blk = left_rows[2 * v * C:2 * (v + 1) * C, 18:18 + 6 * V]
+        mask = np.zeros(6 * V, bool)
+        mask[6 * v:6 * v + 6] = True
+        assert np.all(blk[:, ~mask] == 0.0) and np.any(blk[:, mask] != 0.0)
+
+
+def test_dense_jacobian_is_the_derivative(po):
+    V = 2
+    w, l, r, _, start = synth.make_stereo_views(views=V)
+    J = po.stereo_jacobian_dense(start, 5, w, V)
+    C = len(w)
+    rng = np.random.default_rng(0)
+    d = rng.normal(size=len(start)) * 1e-5
+    d[18:18 + 6 * V] = 0          # those columns are deliberately incomplete (see above)
+    e0 = po.stereo_residual(start - d, 5, w, l, r)
+    e1 = po.stereo_residual(start + d, 5, w, l, r)
+    assert np.allclose((e1 - e0) / 2, J @ d, atol=1e-7 * np.abs(J @ d).max() + 1e-10)
+
+
+def test_mono_on_reference_corners(po, corners):
+    world, img = corners["world_mono"], corners["mono"]
+    x0 = homography_start(world, img, (1920, 1080))   # Test/demo.cpp:71
+    res, J = po.mono_residual_jacobian_dense(x0, world, img)
+    assert res.shape == (2 * 4 * 48,) and J.shape == (384, 9 + 24)
+    assert np.sqrt((res ** 2).mean()) < 15.0      # the start is within a few pixels
+    # residual is observed - projected and J its derivative (CMonocularCameraCalibration.cpp:821)
+    d = np.random.default_rng(1).normal(size=len(x0)) * 1e-6
+    r1, _ = po.mono_residual_jacobian_dense(x0 + d, world, img, want_jacobian=False)
+    assert np.allclose(r1 - res, J @ d, atol=1e-6 * np.abs(J @ d).max() + 1e-11)
+    # a few damped Gauss-Newton steps bring the reprojection error under a pixel
+    x = x0.copy()
+    for _ in range(10):
+        res, J = po.mono_residual_jacobian_dense(x, world, img)
+        A = J.T @ J
+        x = x - np.linalg.solve(A + 1e-3 * np.diag(np.diag(A)), J.T @ res)
+    res, _ = po.mono_residual_jacobian_dense(x, world, img, want_jacobian=False)
+    assert np.sqrt((res ** 2).mean()) < 1.0
