@@ -37,6 +37,8 @@ def parse():
                     help="side of the pair of the sharded leg; 0 disables the leg")
     ap.add_argument("--cpu-iters", type=int, default=30,
                     help="iterations of the CPU baseline sample; 0 disables it")
+    ap.add_argument("--cal-views", type=int, default=2000,
+                    help="views of the calibration leg (11 x 8 board each); 0 disables the leg")
     return ap.parse_args()
 
 
@@ -88,17 +90,20 @@ def main():
 
     # ---- per-kernel durations: the same steps, eager, HIP events on the
     # library's stream around every launch -------------------------------
+    # (the second value kernel_times returns is an event pair with nothing between
+    # its two records: what the pair itself adds to every measured launch)
     ctx.set_options(time_kernels=1)
-    fused, reduce_, per_iter = [], [], []
+    fused, empty, per_iter = [], [], []
     for _ in range(max(2, min(args.steps, 5))):
         ctx.run(args.iters)
         f, s, _ = ctx.kernel_times()
         fused.append(f)
-        reduce_.append(s)
+        empty.append(s)
         per_iter.append(ctx.iteration_times()[0])
     ctx.set_options(time_kernels=0)
-    fused_ms, reduce_ms = float(np.mean(fused)), float(np.mean(reduce_))
-    per_iter = np.mean(np.stack(per_iter), axis=0)
+    raw_ms, pair_ms = float(np.mean(fused)), float(np.mean(empty))
+    fused_ms = raw_ms - pair_ms
+    per_iter = np.mean(np.stack(per_iter), axis=0) - pair_ms
     # algorithmic bytes of one launch of the iteration kernel: source read + write
     # (24 B/pt), target xyz + index + normal (28 B/pt), each touched once
     bytes_fused = 24.0 * n + 28.0 * len(tgt)
@@ -160,6 +165,56 @@ def main():
         }
         sctx.close()
 
+    # ---- calibration leg: residual + Jacobian evaluations of the stereo refinement,
+    # views split over the ranks, one 272-double all-reduce per evaluation ----
+    calibration = None
+    if args.cal_views >= world:
+        from stereovision_amd.calib import HipCalEngine, evaluate_sharded, view_bounds
+        V = args.cal_views
+        cw, cl, cr, _, cstart = synth.make_stereo_views(views=V)
+        vb, ve = view_bounds(V, world, rank)
+        eng = HipCalEngine(cw, cl[vb:ve], cr[vb:ve], f"cuda:{local}")
+        reps = 200
+        if distributed:
+            for _ in range(5):
+                evaluate_sharded(eng, cstart, 5, V, vb, ve, fetch=False)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                evaluate_sharded(eng, cstart, 5, V, vb, ve, fetch=False)
+            barrier()
+            dt = time.perf_counter() - t0
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            eval_ms = float(t.item()) / reps * 1e3
+        else:
+            eng.set_params(cstart, 5)
+            eval_ms = eng.ev.time_eval(reps)      # HIP events around back-to-back evaluations
+        cal_bytes = 56.0 * V * cl.shape[1] + 48.0 * V
+        calibration = {
+            "workload": f"stereo reprojection residual + central-difference Jacobian reduced to "
+                        f"block-sparse normal equations, {V} views x {cl.shape[1]} corners "
+                        f"({4 * V * cl.shape[1]} residual rows, {18 + 6 * V + 6} parameters), "
+                        f"views split over {world} rank(s)",
+            "evaluations_per_s": 1e3 / eval_ms, "ms_per_evaluation": eval_ms, "dtype": "f64",
+            "algorithmic_GBs": cal_bytes / (eval_ms * 1e-3) / 1e9,
+            "scaling": "strong",
+        }
+        if rank == 0 and world == 1 and args.cpu_iters > 0:
+            from oracle import pyoracle as po
+            t0 = time.perf_counter()
+            nrep = 0
+            while time.perf_counter() - t0 < 5.0:
+                po.stereo_eval_sparse(cstart, 5, cw, cl, cr, want_residual=False)
+                nrep += 1
+            calibration["cpu_baseline"] = {
+                "value": nrep / (time.perf_counter() - t0), "unit": "evaluations/s", "cores": 1,
+                "kind": "port",
+                "sample": f"{nrep} block-sparse evaluations of the same {V}-view problem "
+                          "(oracle/cal_oracle.c; the reference's dense Jacobian of "
+                          f"{4 * V * cl.shape[1]} x {18 + 6 * V + 6} doubles cannot be allocated)",
+            }
+
     # ---- CPU baseline: the oracle on the same pair, one thread ------------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_iters > 0:
@@ -204,12 +259,14 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": bytes_fused, "launch_ms": fused_ms,
+                "launch_ms_between_events": raw_ms, "empty_event_pair_ms": pair_ms,
                 "launches_averaged": args.iters,
+                "loop_ms_per_iteration": elapsed / args.steps / args.iters * 1e3,
                 "slowest_launch_ms": slowest_ms,
                 "frac_slowest_launch": bytes_fused / (slowest_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             "cpu_baseline": cpu,
-            "kernels_ms": {"icp_iterate": fused_ms, "reduce_rows": reduce_ms,
+            "kernels_ms": {"icp_iterate": fused_ms,
                            "icp_iterate_per_iteration": [round(float(x), 5) for x in per_iter],
                            "nn1_capped": nn_capped_ms, "nn1_exact": nn_exact_ms},
             "value_searching_every_point_every_iteration": full_search_value,
@@ -219,6 +276,7 @@ def main():
             "grid_build_ms": grid_build_s * 1e3,
             "final_step_norm": info.step_norm,
             "sharded": sharded,
+            "calibration": calibration,
         }
         print(json.dumps(out))
     ctx.close()

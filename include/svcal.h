@@ -67,6 +67,21 @@ int svcal_eval(svcal_ctx *ctx);
 /* Copies the results of the last svcal_eval into the caller's blocks. */
 int svcal_fetch(svcal_ctx *ctx, svcal_blocks *out);
 
+/* Runs the context's work on the caller's HIP stream (use_own = 0; NULL is the
+ * default stream) or back on the context's own stream (use_own = 1). */
+int svcal_set_stream(svcal_ctx *ctx, void *hip_stream, int use_own);
+
+/* Views split over several contexts (one per GPU; no counterpart in the reference):
+ * every context holds the full shared parameters and its own views' extrinsics.
+ * After svcal_eval, svcal_shard_export copies the 272 sums over this context's
+ * views (the 16 x 16 upper triangles of [J | e]^T [J | e] for the left and the
+ * right camera) into a caller's device buffer; the caller adds the buffers of all
+ * contexts (an all-reduce) and hands the total back with svcal_shard_import, after
+ * which svcal_fetch returns the shared blocks (LL, RR, RS, SS, gL, gR, gS, |e|^2)
+ * of the whole problem and the per-view blocks (LE, EE, gE) of this context's views. */
+int svcal_shard_export(svcal_ctx *ctx, double *dev_sums272);
+int svcal_shard_import(svcal_ctx *ctx, const double *dev_sums272);
+
 /* Average duration (ms) of `reps` back-to-back svcal_eval launches. */
 int svcal_time_eval(svcal_ctx *ctx, int reps, double *avg_ms);
 

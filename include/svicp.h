@@ -139,11 +139,15 @@ int svicp_knn(svicp_ctx *ctx, const float *query_aos, int64_t n, int k,
 
 /* ---- sharded registration (one context per GPU) ---------------------- */
 /* A large registration shards the source over ranks; every rank holds the
- * whole target.  Per iteration each rank calls svicp_shard_accumulate, the
- * caller sums the 32-double blocks of all ranks (RCCL all-reduce), and each
- * rank calls svicp_shard_update with the sum.  The reference has no multi-
- * device path; these split CPoint2PlaneICP::singleRun (CPoint2PlaneICP.cpp:63-120)
- * at the one point where ranks exchange data. */
+ * whole target.  The library keeps, per rank, running totals of the 32 sums
+ * of the normal equations (21 upper-triangle JtJ entries, 6 Jtr entries,
+ * {inliers, sum w b^2, sum w}, padding) and per iteration only their CHANGE:
+ * points whose correspondence and position did not change contribute zero.
+ * Per iteration each rank calls svicp_shard_accumulate, the caller adds the
+ * 32-double change blocks of all ranks (RCCL all-reduce), and each rank calls
+ * svicp_shard_update with the total.  The reference has no multi-device path;
+ * these split CPoint2PlaneICP::singleRun (CPoint2PlaneICP.cpp:63-120) at the
+ * one point where ranks exchange data. */
 
 /* Launches on `hip_stream` (a hipStream_t, e.g. the caller framework's
  * current stream) from now on.  NULL is the device's default stream, not
@@ -155,28 +159,33 @@ int svicp_use_own_stream(svicp_ctx *ctx);
 /* Resets the accumulated transform and the iteration counter. */
 int svicp_shard_begin(svicp_ctx *ctx);
 
-/* Transforms this rank's source shard by the previous update, finds
- * correspondences and writes this rank's partial sums: 21 upper-triangle
- * JtJ entries, 6 Jtr entries, {inliers, sum w b^2, sum w}, padding to 32
- * doubles, to device memory `dev_partial32`. */
+/* Solves the system of the previous iteration (from the totals every rank
+ * holds identically), transforms this rank's source shard by it, finds
+ * correspondences, and copies this rank's change of the 32 sums in this
+ * iteration to device memory `dev_partial32`.  At most 1024 iterations per
+ * svicp_shard_begin. */
 int svicp_shard_accumulate(svicp_ctx *ctx, double *dev_partial32);
 
-/* Solves from the globally summed block (device memory) and updates the
- * rank's copy of R, T and the accumulated transform. */
+/* Takes the change summed over all ranks (device memory); the next
+ * svicp_shard_accumulate, or svicp_shard_finish, adds it to the running totals
+ * and solves. */
 int svicp_shard_update(svicp_ctx *ctx, const double *dev_sum32);
 
-/* Copies out the accumulated transform after the last svicp_shard_update. */
+/* Solves the last iteration's system and copies out the accumulated transform. */
 int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info);
 
 /* ---- measurement ----------------------------------------------------- */
 
-/* Average duration in milliseconds, over the last svicp_run made with
- * options.time_kernels = 1, of the per-iteration correspondence+accumulate
- * kernel and of the solve kernel, and the number of launches averaged. */
+/* Over the last svicp_run made with options.time_kernels = 1: the average
+ * time in milliseconds between the two HIP events recorded around each launch
+ * of the iteration kernel (fused_ms), the average time between two events
+ * recorded back to back with nothing between them (solve_ms: what an event
+ * pair adds to every measured launch; the solve runs inside the iteration
+ * kernel), and the number of launches averaged. */
 int svicp_kernel_times(svicp_ctx *ctx, double *fused_ms, double *solve_ms, int *launches);
 
-/* Per-iteration durations (milliseconds) of the same two kernels over the last
- * timed svicp_run: `iterations` entries each.  Either pointer may be NULL. */
+/* The same two quantities per iteration over the last timed svicp_run:
+ * `iterations` entries each.  Either pointer may be NULL. */
 int svicp_iteration_times(svicp_ctx *ctx, double *fused_ms_out, double *solve_ms_out);
 
 /* Runs the standalone 1-NN kernel `reps` times over the resident source and

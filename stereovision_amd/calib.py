@@ -34,6 +34,9 @@ CAL_SYMBOLS = {
     "svcal_eval": (C.c_int, [C.c_void_p]),
     "svcal_fetch": (C.c_int, [C.c_void_p, C.POINTER(_Blocks)]),
     "svcal_time_eval": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "svcal_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "svcal_shard_export": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "svcal_shard_import": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 
@@ -125,6 +128,19 @@ class ReprojectionEvaluator:
         self.eval()
         return self.fetch(want_residual)
 
+    def set_stream(self, handle=None):
+        """handle: a HIP stream handle (0 = the default stream); None: the context's own."""
+        if handle is None:
+            self._check(self._lib.svcal_set_stream(self._h, None, 1))
+        else:
+            self._check(self._lib.svcal_set_stream(self._h, C.c_void_p(int(handle)), 0))
+
+    def shard_export(self, dev_ptr):
+        self._check(self._lib.svcal_shard_export(self._h, C.c_void_p(int(dev_ptr))))
+
+    def shard_import(self, dev_ptr):
+        self._check(self._lib.svcal_shard_import(self._h, C.c_void_p(int(dev_ptr))))
+
     def time_eval(self, reps=20):
         ms = C.c_double()
         self._check(self._lib.svcal_time_eval(self._h, int(reps), C.byref(ms)))
@@ -190,3 +206,69 @@ def lm_refine(evaluator, params, k=5, max_iter=100, verbose=False):
             lam *= v
             v *= 2.0
     return x, np.sqrt(err2)
+
+
+def split_views(params, k, V, stereo, begin, end):
+    """The parameter vector of views [begin, end) of a V-view problem."""
+    nI = 4 + k
+    e0 = 2 * nI if stereo else nI
+    p = np.asarray(params, np.float64)
+    parts = [p[:e0], p[e0 + 6 * begin:e0 + 6 * end]]
+    if stereo:
+        parts.append(p[e0 + 6 * V:])
+    return np.concatenate(parts)
+
+
+def view_bounds(V, world, rank):
+    """Contiguous view range of a rank: sizes differ by at most one."""
+    base, extra = divmod(V, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+class HipCalEngine:
+    """One rank's views on one GPU.  export_sums / import_sums move the 272 sums over the
+    rank's views between the library and a torch tensor on the same device."""
+
+    def __init__(self, world_xy, left_xy, right_xy, device):
+        import torch
+        self.dev = torch.device(device)
+        self.ev = ReprojectionEvaluator(world_xy, left_xy, right_xy, self.dev.index or 0)
+        self.stereo = self.ev.stereo
+        self.buf = torch.zeros(272, dtype=torch.float64, device=self.dev)
+        self.ev.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def set_params(self, p, k):
+        self.ev.set_params(p, k)
+
+    def eval(self):
+        self.ev.eval()
+
+    def export_sums(self):
+        self.ev.shard_export(self.buf.data_ptr())
+        return self.buf
+
+    def import_sums(self, t):
+        self.ev.shard_import(t.data_ptr())
+
+    def fetch(self):
+        return self.ev.fetch(want_residual=False)
+
+
+def evaluate_sharded(engine, params, k, V_total, begin, end, group=None, fetch=True):
+    """One evaluation with the views split over the ranks of a torch.distributed group.
+    The only exchange is one all-reduce of the engine's sums (RCCL on the device for the
+    nccl backend; staged through the host for gloo).  Returns the shared blocks of the whole
+    problem and the per-view blocks of this rank's views."""
+    import torch.distributed as dist
+    engine.set_params(split_views(params, k, V_total, engine.stereo, begin, end), k)
+    engine.eval()
+    t = engine.export_sums()
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, group=group)
+    engine.import_sums(t)
+    return engine.fetch() if fetch else None

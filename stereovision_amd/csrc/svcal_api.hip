@@ -16,7 +16,7 @@ using namespace svcal;
 
 struct svcal_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, own_stream = nullptr;
     std::string err;
     int V = 0, C = 0, k = 5, stereo = 0;
     bool have_obs = false, have_params = false, evaluated = false;
@@ -80,8 +80,9 @@ int svcal_create(int device_id, svcal_ctx **out)
         return cfail(nullptr, SVICP_ERR_NO_DEVICE, "svcal_create: the library holds gfx950 code only");
     ctx = new svcal_ctx();
     ctx->device = device_id;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return cfail(nullptr, SVICP_ERR_HIP, "hipStreamCreate", e); }
+    ctx->stream = ctx->own_stream;
     *out = ctx;
     return SVICP_OK;
 }
@@ -93,7 +94,7 @@ int svcal_destroy(svcal_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_obs(ctx);
     if (ctx->params) (void)hipFree(ctx->params);
-    (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SVICP_OK;
 }
@@ -211,6 +212,35 @@ int svcal_fetch(svcal_ctx *ctx, svcal_blocks *out)
         }
     }
     out->sq_residual = GL[at(15, 15)] + (ctx->stereo ? GR[at(15, 15)] : 0.0);
+    return SVICP_OK;
+}
+
+int svcal_set_stream(svcal_ctx *ctx, void *hip_stream, int use_own)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    CHK(hipSetDevice(ctx->device));
+    CHK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = use_own ? ctx->own_stream : (hipStream_t)hip_stream;
+    return SVICP_OK;
+}
+
+int svcal_shard_export(svcal_ctx *ctx, double *dev_sums272)
+{
+    if (!ctx || !dev_sums272) return cfail(ctx, SVICP_ERR_ARG, "svcal_shard_export: NULL argument");
+    if (!ctx->evaluated) return cfail(ctx, SVICP_ERR_ARG, "svcal_shard_export: nothing evaluated yet");
+    CHK(hipSetDevice(ctx->device));
+    CHK(hipMemcpyAsync(dev_sums272, ctx->gram_sum, sizeof(double) * 2 * kGram, hipMemcpyDeviceToDevice,
+                       ctx->stream));
+    return SVICP_OK;
+}
+
+int svcal_shard_import(svcal_ctx *ctx, const double *dev_sums272)
+{
+    if (!ctx || !dev_sums272) return cfail(ctx, SVICP_ERR_ARG, "svcal_shard_import: NULL argument");
+    if (!ctx->evaluated) return cfail(ctx, SVICP_ERR_ARG, "svcal_shard_import: nothing evaluated yet");
+    CHK(hipSetDevice(ctx->device));
+    CHK(hipMemcpyAsync(ctx->gram_sum, dev_sums272, sizeof(double) * 2 * kGram, hipMemcpyDeviceToDevice,
+                       ctx->stream));
     return SVICP_OK;
 }
 

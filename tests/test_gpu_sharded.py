@@ -90,3 +90,39 @@ def test_two_processes_share_one_gpu_over_gloo(tmp_path):
     full.set_source(src)
     T_full, _ = full.run(5)
     assert np.abs(T0 - T_full).max() < 1e-10
+
+
+def test_calibration_views_split_over_two_contexts(po):
+    """Two contexts on one device hold 3 and 4 of 7 views; their 272 sums are added as the
+    all-reduce would and handed back."""
+    import torch
+    from stereovision_amd import synth
+    from stereovision_amd.calib import (HipCalEngine, ReprojectionEvaluator, split_views,
+                                        view_bounds)
+    V = 7
+    w, l, r, _, start = synth.make_stereo_views(views=V)
+    whole = ReprojectionEvaluator(w, l, r).evaluate(start, want_residual=False)
+    engines, spans = [], []
+    for rank in range(2):
+        b, e = view_bounds(V, 2, rank)
+        eng = HipCalEngine(w, l[b:e], r[b:e], "cuda:0")
+        eng.set_params(split_views(start, 5, V, True, b, e), 5)
+        eng.eval()
+        engines.append(eng)
+        spans.append((b, e))
+    total = torch.zeros(272, dtype=torch.float64, device="cuda:0")
+    for eng in engines:
+        total += eng.export_sums()
+    outs = []
+    for eng in engines:
+        eng.import_sums(total)
+        outs.append(eng.fetch())
+    for n in ("LL", "RR", "RS", "SS", "gL", "gR", "gS"):
+        assert np.array_equal(outs[0][n], outs[1][n])
+        assert np.allclose(outs[0][n], whole[n], rtol=1e-13, atol=1e-13 * np.abs(whole[n]).max())
+    assert outs[0]["sq_residual"] == pytest.approx(whole["sq_residual"], rel=1e-13)
+    for out, (b, e) in zip(outs, spans):
+        for n in ("LE", "EE", "gE"):
+            assert np.array_equal(out[n], whole[n][b:e])
+    want = po.stereo_eval_sparse(start, 5, w, l, r, False)
+    assert np.abs(outs[0]["LL"] - want["LL"]).max() / np.abs(want["LL"]).max() < 1e-6

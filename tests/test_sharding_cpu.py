@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -90,3 +91,83 @@ def test_two_ranks_match_the_unsharded_oracle(po, synth32, tmp_path):
     assert np.array_equal(T0, T1), "every rank must hold the same transform"
     r = po.icp_point2plane(po.KDTree(synth32["target"]), synth32["normals"], synth32["source"], 4)
     assert np.allclose(T0, r["trans"], rtol=0, atol=1e-9)
+
+
+# ---- calibration: views split over the ranks ---------------------------------
+SHARED = ("LL", "RR", "RS", "SS", "gL", "gR", "gS")
+
+
+class OracleCalEngine:
+    """CPU engine for evaluate_sharded: the oracle on this rank's views; the sums that
+    cross ranks are the shared blocks and |e|^2, flattened."""
+
+    def __init__(self, po, world, left, right):
+        self.po, self.w, self.l, self.r, self.stereo = po, world, left, right, True
+
+    def set_params(self, p, k):
+        self.p, self.k = p, k
+
+    def eval(self):
+        self.out = self.po.stereo_eval_sparse(self.p, self.k, self.w, self.l, self.r, False)
+
+    def export_sums(self):
+        flat = [self.out[n].ravel() for n in SHARED] + [np.array([self.out["sq_residual"]])]
+        return torch.from_numpy(np.concatenate(flat))
+
+    def import_sums(self, t):
+        v, o = t.numpy(), 0
+        for n in SHARED:
+            sz = self.out[n].size
+            self.out[n] = v[o:o + sz].reshape(self.out[n].shape).copy()
+            o += sz
+        self.out["sq_residual"] = float(v[o])
+
+    def fetch(self):
+        return self.out
+
+
+def _cal_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as po
+    from stereovision_amd import synth
+    from stereovision_amd.calib import evaluate_sharded, view_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    V = 7
+    w, l, r, _, start = synth.make_stereo_views(views=V)
+    b, e = view_bounds(V, world, rank)
+    eng = OracleCalEngine(po, w, l[b:e], r[b:e])
+    out = evaluate_sharded(eng, start, 5, V, b, e)
+    np.savez(os.path.join(out_dir, f"cal{rank}.npz"), begin=b, end=e,
+             **{n: out[n] for n in SHARED + ("LE", "EE", "gE")}, sq=out["sq_residual"])
+    dist.destroy_process_group()
+
+
+def test_view_bounds_and_split():
+    from stereovision_amd.calib import split_views, view_bounds
+    for V in (1, 7, 2000):
+        for w in (1, 2, 3, 8):
+            spans = [view_bounds(V, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == V
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+    p = np.arange(18 + 6 * 5 + 6, dtype=np.float64)
+    q = split_views(p, 5, 5, True, 1, 3)
+    assert np.array_equal(q, np.r_[p[:18], p[24:36], p[-6:]])
+
+
+def test_calibration_views_split_over_two_ranks(po, tmp_path):
+    from stereovision_amd import synth
+    port = _free_port()
+    mp.spawn(_cal_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w, l, r, _, start = synth.make_stereo_views(views=7)
+    whole = po.stereo_eval_sparse(start, 5, w, l, r, False)
+    parts = [np.load(tmp_path / f"cal{i}.npz") for i in range(2)]
+    for n in SHARED:
+        assert np.array_equal(parts[0][n], parts[1][n])
+        assert np.allclose(parts[0][n], whole[n], rtol=1e-13, atol=1e-13 * np.abs(whole[n]).max())
+    assert float(parts[0]["sq"]) == pytest.approx(whole["sq_residual"], rel=1e-13)
+    for part in parts:
+        b, e = int(part["begin"]), int(part["end"])
+        for n in ("LE", "EE", "gE"):
+            assert np.array_equal(part[n], whole[n][b:e])

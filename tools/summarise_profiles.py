@@ -1,0 +1,106 @@
+"""Turns rocprofv3 output directories into the summaries kept under profiles/.
+
+  python tools/summarise_profiles.py stats  <rocprof dir> <out prefix>
+      copies *_kernel_stats.csv (kernel names shortened) to <prefix>_kernel_stats.csv and writes
+      <prefix>_kernel_by_grid.csv: calls and average duration per (kernel, grid size), from
+      *_kernel_trace.csv -- the stats file mixes launches of one kernel over different sizes.
+  python tools/summarise_profiles.py traffic <fetch dir> <write dir> <out json> [algorithmic bytes]
+      mean FETCH_SIZE / WRITE_SIZE per launch per (kernel, grid size) from two --pmc passes.
+      FETCH_SIZE is in units of 1 KB and on gfx950 tallies a 128-byte read request as 64 bytes:
+      bytes = 2 * 1024 * FETCH_SIZE.  WRITE_SIZE: bytes = 1024 * WRITE_SIZE.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return hits
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)                 # drop the argument list
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", name)
+    return name[:120]
+
+
+def stats(src, prefix):
+    rows = []
+    for f in find(src, "kernel_stats.csv"):
+        with open(f) as fh:
+            rows += list(csv.DictReader(fh))
+    with open(prefix + "_kernel_stats.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                        r["Percentage"], r["MinNs"], r["MaxNs"]])
+    agg = defaultdict(list)
+    for f in find(src, "kernel_trace.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                grid = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1))
+                agg[(short(r["Kernel_Name"]), grid)].append(
+                    int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(prefix + "_kernel_by_grid.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "GridThreads", "Calls", "AverageNs", "MinNs", "MaxNs"])
+        for (name, grid), d in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([name, grid, len(d), round(sum(d) / len(d), 1), min(d), max(d)])
+
+
+def counters(d, counter):
+    agg = defaultdict(list)
+    for f in find(d, "counter_collection.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] != counter:
+                    continue
+                agg[(short(r["Kernel_Name"]), int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return agg
+
+
+def traffic(fetch_dir, write_dir, out, algorithmic=None):
+    fe, wr = counters(fetch_dir, "FETCH_SIZE"), counters(write_dir, "WRITE_SIZE")
+    res = {}
+    for key in sorted(set(fe) | set(wr)):
+        f = sum(fe[key]) / len(fe[key]) if key in fe else 0.0
+        w = sum(wr[key]) / len(wr[key]) if key in wr else 0.0
+        res[f"{key[0]} grid={key[1]}"] = {
+            "launches": len(fe.get(key, wr.get(key))), "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+            "bytes_per_launch": 2.0 * 1024.0 * f + 1024.0 * w}
+    doc = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; mean per "
+                     "launch per (kernel, grid size); FETCH_SIZE doubled (gfx950 tallies 128-byte "
+                     "read requests as 64 bytes), WRITE_SIZE as reported, both in KB",
+           "per_kernel": res}
+    if algorithmic:
+        doc["algorithmic_bytes_per_launch"] = float(algorithmic)
+    # the figure bench.py reports: one 30-iteration step of the benchmark launches the
+    # iteration kernel once searching every point (<false, false>) and 29 times with the
+    # shortcut for points whose correspondence provably did not change (<true, true>)
+    it = {k: v for k, v in res.items() if "icp_iterate_kernel" in k}
+    if it:
+        big = max(int(k.split("grid=")[1]) for k in it)
+        first = [v for k, v in it.items() if "<false, false" in k and k.endswith(f"grid={big}")]
+        rest = [v for k, v in it.items() if "<true, true" in k and k.endswith(f"grid={big}")]
+        if first and rest:
+            doc["icp_iterate_kernel_bytes_per_launch"] = (
+                first[0]["bytes_per_launch"] + 29.0 * rest[0]["bytes_per_launch"]) / 30.0
+            doc["weighting"] = "1 launch <false, false> : 29 launches <true, true>, as in one step"
+    with open(out, "w") as fh:
+        json.dump(doc, fh, indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "traffic":
+        traffic(*sys.argv[2:6])
