@@ -174,6 +174,28 @@ int svicp_shard_update(svicp_ctx *ctx, const double *dev_sum32);
 /* Solves the last iteration's system and copies out the accumulated transform. */
 int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info);
 
+/* ---- batches of independent pairs (one launch per iteration for all) ---- */
+/* Many small registrations do not fill the GPU one at a time.  A batch takes
+ * contexts that already hold their target and source (all on one device) and
+ * advances all of them with one kernel launch per iteration; every pair keeps
+ * its own grid, state and sums, so each result equals what svicp_run on that
+ * context returns.  The reference registers one pair per CPoint2PlaneICP::run
+ * call (test.cpp:22-25); a caller with many pairs loops over it.  The batch
+ * uses the stream and the use_graph / coherent options of ctxs[0]; contexts
+ * must outlive the batch and must not be used by other threads during a run.
+ * Afterwards every context is in the state svicp_run leaves it in
+ * (svicp_get_source, svicp_get_history work per pair). */
+typedef struct svicp_batch svicp_batch;
+int svicp_batch_create(svicp_ctx **ctxs, int count, svicp_batch **out);
+int svicp_batch_destroy(svicp_batch *batch);
+const char *svicp_batch_last_error(const svicp_batch *batch);
+/* T_out: count x 16 doubles (row-major 4x4 per pair); info_out: count entries or NULL.
+ * Returns SVICP_ERR_SINGULAR if any pair's system was singular (that pair's
+ * info.status says which). */
+int svicp_batch_run(svicp_batch *batch, int iterations, double *T_out, svicp_info *info_out);
+/* Device time (ms, HIP events on the batch's stream) of the last svicp_batch_run's loop. */
+int svicp_batch_last_ms(const svicp_batch *batch, double *ms);
+
 /* ---- measurement ----------------------------------------------------- */
 
 /* Over the last svicp_run made with options.time_kernels = 1: the average

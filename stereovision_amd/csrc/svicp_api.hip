@@ -82,6 +82,20 @@ struct svicp_ctx {
     int shard_iter = 0;
 };
 
+
+// Many independent registrations advanced by one launch per iteration.
+struct svicp_batch {
+    std::vector<svicp_ctx *> ctxs;
+    svicp_ctx *lead = nullptr;          // device, stream and error text of the batch
+    DevBuf pairs, block_map, states;
+    IcpState *h_states = nullptr;       // pinned
+    int total_blocks = 0;
+    int iters_cap = 0;
+    hipGraphExec_t gexec = nullptr;
+    int g_iters = -1;
+    double last_ms = 0.0;
+};
+
 namespace {
 
 int fail(svicp_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
@@ -924,6 +938,171 @@ int svicp_time_nn(svicp_ctx *ctx, int exact, int reps, double *avg_ms)
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     *avg_ms = (double)ms / reps;
+    return SVICP_OK;
+}
+
+/* ---- batches of independent pairs -------------------------------------- */
+
+int svicp_batch_create(svicp_ctx **ctxs, int count, svicp_batch **out)
+{
+    if (!out) return SVICP_ERR_ARG;
+    *out = nullptr;
+    if (!ctxs || count < 1 || !ctxs[0]) return fail(nullptr, SVICP_ERR_ARG, "svicp_batch_create: bad argument");
+    svicp_ctx *ctx = ctxs[0];
+    for (int i = 0; i < count; ++i) {
+        if (!ctxs[i] || ctxs[i]->device != ctx->device)
+            return fail(ctx, SVICP_ERR_ARG, "svicp_batch_create: every context must be on the same device");
+        if (!ctxs[i]->have_target || !ctxs[i]->have_source)
+            return fail(ctx, SVICP_ERR_ARG, "svicp_batch_create: set every pair's target and source first");
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return fail(ctx, SVICP_ERR_ARG, "svicp_batch_create: a context appears twice");
+    }
+    svicp_batch *b = new svicp_batch();
+    b->ctxs.assign(ctxs, ctxs + count);
+    b->lead = ctx;
+    *out = b;
+    return SVICP_OK;
+}
+
+int svicp_batch_destroy(svicp_batch *b)
+{
+    if (!b) return SVICP_OK;
+    (void)hipSetDevice(b->lead->device);
+    (void)hipStreamSynchronize(b->lead->stream);
+    if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
+    b->pairs.release(); b->block_map.release(); b->states.release();
+    if (b->h_states) (void)hipHostFree(b->h_states);
+    delete b;
+    return SVICP_OK;
+}
+
+const char *svicp_batch_last_error(const svicp_batch *b)
+{
+    return b ? b->lead->err.c_str() : g_create_error.c_str();
+}
+
+int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *info_out)
+{
+    if (!b) return SVICP_ERR_ARG;
+    svicp_ctx *ctx = b->lead;
+    if (iterations < 1 || !T_out) return fail(ctx, SVICP_ERR_ARG, "svicp_batch_run: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int count = (int)b->ctxs.size();
+
+    // (re)build the device tables when any pair's buffers changed
+    std::vector<BatchPair> hp(count);
+    std::vector<int2> map;
+    for (int i = 0; i < count; ++i) {
+        svicp_ctx *c = b->ctxs[i];
+        if (!c->have_target || !c->have_source)
+            return fail(ctx, SVICP_ERR_ARG, "svicp_batch_run: a pair lost its target or source");
+        HIPCHK(hipStreamSynchronize(c->stream));     // set-up work of the pair is done
+        int rc = ensure_iteration_buffers(c, iterations);
+        if (rc) { ctx->err = c->err; return rc; }
+        const float thr = c->opt.dist_threshold;
+        BatchPair &P = hp[i];
+        P.g = c->g;
+        P.x0 = c->sx0.as<float>(); P.y0 = c->sy0.as<float>(); P.z0 = c->sz0.as<float>();
+        P.wx = c->wx.as<float>(); P.wy = c->wy.as<float>(); P.wz = c->wz.as<float>();
+        P.n = (int)c->n; P.nb = c->nb;
+        P.totals = c->totals.as<double>(); P.deltas = c->deltas.as<double>();
+        P.st = c->state.as<IcpState>();
+        P.X_hist = c->xhist.as<double>(); P.info_hist = c->ihist.as<double>();
+        P.cp.thr = thr;
+        P.cp.root_hi = std::sqrt(thr) * 1.00001f;
+        P.cp.cov = std::sqrt(thr) * 1.001f;
+        P.ps.tp = c->st_tp.as<float4>(); P.ps.nv = c->st_nv.as<float4>(); P.ps.lb = c->st_lb.as<float>();
+        P.partials = c->partials.as<double>();
+        for (int t = 0; t < c->nb; ++t) map.push_back(make_int2(i, t));
+    }
+    void *pb = b->pairs.p, *mb = b->block_map.p;
+    HIPCHK(b->pairs.reserve(sizeof(BatchPair) * count));
+    HIPCHK(b->block_map.reserve(sizeof(int2) * map.size()));
+    HIPCHK(b->states.reserve(sizeof(IcpState) * count));
+    if (!b->h_states) HIPCHK(hipHostMalloc((void **)&b->h_states, sizeof(IcpState) * count, 0));
+    HIPCHK(hipMemcpyAsync(b->pairs.p, hp.data(), sizeof(BatchPair) * count, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(b->block_map.p, map.data(), sizeof(int2) * map.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));       // hp and map go out of scope
+    const bool coherent = ctx->opt.coherent != 0;
+    const int total = (int)map.size();
+    if (pb != b->pairs.p || mb != b->block_map.p || total != b->total_blocks || b->g_iters != iterations) {
+        if (b->gexec) { (void)hipGraphExecDestroy(b->gexec); b->gexec = nullptr; }
+        b->g_iters = -1;
+    }
+    b->total_blocks = total;
+
+    auto enqueue = [&]() -> int {
+        const BatchPair *dp = b->pairs.as<BatchPair>();
+        const int2 *dm = b->block_map.as<int2>();
+        hipLaunchKernelGGL(batch_reset_kernel, dim3(count), dim3(64), 0, ctx->stream, dp, iterations);
+        LAUNCHCHK("batch_reset_kernel");
+        for (int k = 0; k < iterations; ++k) {
+            if (k == 0)
+                hipLaunchKernelGGL((icp_iterate_batch_kernel<false, false, 4>), dim3(total), dim3(kItThreads), 0, ctx->stream, dp, dm, k);
+            else if (coherent)
+                hipLaunchKernelGGL((icp_iterate_batch_kernel<true, true, 4>), dim3(total), dim3(kItThreads), 0, ctx->stream, dp, dm, k);
+            else
+                hipLaunchKernelGGL((icp_iterate_batch_kernel<true, false, 4>), dim3(total), dim3(kItThreads), 0, ctx->stream, dp, dm, k);
+            LAUNCHCHK("icp_iterate_batch_kernel");
+        }
+        hipLaunchKernelGGL(batch_solve_kernel, dim3(count), dim3(64), 0, ctx->stream, dp, iterations - 1);
+        LAUNCHCHK("batch_solve_kernel");
+        const long long words = (long long)count * (sizeof(IcpState) / sizeof(double));
+        hipLaunchKernelGGL(batch_collect_kernel, dim3(cdiv(words, 256)), dim3(256), 0, ctx->stream, dp, count, b->states.as<IcpState>());
+        LAUNCHCHK("batch_collect_kernel");
+        return SVICP_OK;
+    };
+
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, ctx->stream));
+    if (ctx->opt.use_graph) {
+        if (!b->gexec) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue();
+            hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (e != hipSuccess) return fail(ctx, SVICP_ERR_HIP, "hipStreamEndCapture", e);
+            e = hipGraphInstantiate(&b->gexec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { b->gexec = nullptr; return fail(ctx, SVICP_ERR_HIP, "hipGraphInstantiate", e); }
+            b->g_iters = iterations;
+        }
+        HIPCHK(hipGraphLaunch(b->gexec, ctx->stream));
+    } else {
+        int rc = enqueue();
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(e1, ctx->stream));
+    HIPCHK(hipMemcpyAsync(b->h_states, b->states.p, sizeof(IcpState) * count, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    b->last_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+
+    int worst = SVICP_OK;
+    for (int i = 0; i < count; ++i) {
+        svicp_ctx *c = b->ctxs[i];
+        *c->h_state = b->h_states[i];
+        c->cur = iterations > 1 ? 1 : 0;
+        c->last_iters = iterations;
+        std::memcpy(T_out + 16 * (size_t)i, c->h_state->Trans, sizeof(double) * 16);
+        if (info_out) fill_info(c, iterations, info_out + i);
+        if (c->h_state->status == SVICP_ERR_SINGULAR) worst = SVICP_ERR_SINGULAR;
+    }
+    if (worst != SVICP_OK)
+        return fail(ctx, worst, "svicp_batch_run: a pair's normal matrix was not positive definite (see info[i].status)");
+    return SVICP_OK;
+}
+
+int svicp_batch_last_ms(const svicp_batch *b, double *ms)
+{
+    if (!b || !ms) return SVICP_ERR_ARG;
+    *ms = b->last_ms;
     return SVICP_OK;
 }
 

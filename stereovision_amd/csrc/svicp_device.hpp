@@ -561,13 +561,23 @@ __device__ inline void solve_and_update(const double *base, const double *delta,
 //     their change is added to this iteration's delta sums, so no separate
 //     reduction launch is needed; a tile that was skipped adds nothing.
 // ------------------------------------------------------------------------
+// Blocks that share an XCD (blockIdx % 8 equal) take neighbouring work items,
+// so each XCD's L2 sees one contiguous stretch of the Morton-ordered source.
+__device__ __forceinline__ int xcd_contiguous(int block, int nb)
+{
+    const int q8 = nb >> 3, r8 = nb & 7;
+    const int xcd = block & 7, within = block >> 3;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+}
+
+// The work of one block: tile `tile` of a source of `nb` tiles.
 template <bool APPLY, bool CERTIFY, int CH>
-__global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
-    GridDesc g, const float *__restrict__ sx_in, const float *__restrict__ sy_in,
+__device__ __forceinline__ void iterate_tile(
+    const GridDesc &g, const float *__restrict__ sx_in, const float *__restrict__ sy_in,
     const float *__restrict__ sz_in, float *__restrict__ sx_out, float *__restrict__ sy_out,
     float *__restrict__ sz_out, int n, double *__restrict__ totals, double *__restrict__ deltas,
-    IcpState *st, double *X_hist, double *info_hist, int iter, CohParams cp, PointState ps,
-    double *__restrict__ partials)
+    IcpState *st, double *X_hist, double *info_hist, int iter, const CohParams &cp,
+    const PointState &ps, double *__restrict__ partials, const int tile, const int nb)
 {
     constexpr int NP = kItPoints * kItHalves;         // points per thread
     __shared__ float4 queue[kItTile];                 // {x, y, z, index in tile}
@@ -575,12 +585,6 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     __shared__ int wcount[NP][kItThreads / 64];
     __shared__ double shRT[12];
 
-    // blocks that share an XCD (blockIdx % 8 equal) take neighbouring tiles,
-    // so each XCD's L2 sees one contiguous stretch of the Morton-ordered source
-    const int nb = (int)gridDim.x;
-    const int q8 = nb >> 3, r8 = nb & 7;
-    const int xcd = (int)blockIdx.x & 7, within = (int)blockIdx.x >> 3;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
     const long long tile0 = (long long)tile * kItTile;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool in_place = sx_in == sx_out;
@@ -757,6 +761,93 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
         const double d = s - old_row;
         if (d != 0.0) atomicAdd(deltas + (size_t)iter * kNumSums + threadIdx.x, d);
     }
+}
+
+template <bool APPLY, bool CERTIFY, int CH>
+__global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
+    GridDesc g, const float *__restrict__ sx_in, const float *__restrict__ sy_in,
+    const float *__restrict__ sz_in, float *__restrict__ sx_out, float *__restrict__ sy_out,
+    float *__restrict__ sz_out, int n, double *__restrict__ totals, double *__restrict__ deltas,
+    IcpState *st, double *X_hist, double *info_hist, int iter, CohParams cp, PointState ps,
+    double *__restrict__ partials)
+{
+    const int nb = (int)gridDim.x;
+    iterate_tile<APPLY, CERTIFY, CH>(g, sx_in, sy_in, sz_in, sx_out, sy_out, sz_out, n, totals,
+                                     deltas, st, X_hist, info_hist, iter, cp, ps, partials,
+                                     xcd_contiguous((int)blockIdx.x, nb), nb);
+}
+
+// ------------------------------------------------------------------------
+// Many independent registrations in one launch per iteration: block b works on
+// tile block_map[b].y of pair block_map[b].x.  Each pair has its own grid,
+// source, state and sums; nothing crosses pairs.
+// ------------------------------------------------------------------------
+struct BatchPair {
+    GridDesc g;
+    const float *x0, *y0, *z0;   // the source as set
+    float *wx, *wy, *wz;         // the moving copy
+    int n, nb;
+    double *totals, *deltas;
+    IcpState *st;
+    double *X_hist, *info_hist;
+    CohParams cp;
+    PointState ps;
+    double *partials;
+};
+
+template <bool APPLY, bool CERTIFY, int CH>
+__global__ __launch_bounds__(kItThreads, 4) void icp_iterate_batch_kernel(
+    const BatchPair *__restrict__ pairs, const int2 *__restrict__ block_map, int iter)
+{
+    const int2 m = block_map[xcd_contiguous((int)blockIdx.x, (int)gridDim.x)];
+    const BatchPair *P = pairs + m.x;
+    const GridDesc g = P->g;
+    const CohParams cp = P->cp;
+    const PointState ps = P->ps;
+    float *wx = P->wx, *wy = P->wy, *wz = P->wz;
+    // iteration 0 reads the source as set and leaves it alone (the reference
+    // applies the first update at the start of iteration 1), iteration 1 reads
+    // it and writes the moving copy, later ones update the moving copy in place
+    const bool first = iter <= 1;
+    iterate_tile<APPLY, CERTIFY, CH>(g, first ? P->x0 : wx, first ? P->y0 : wy, first ? P->z0 : wz,
+                                     wx, wy, wz, P->n, P->totals, P->deltas, P->st, P->X_hist,
+                                     P->info_hist, iter, cp, ps, P->partials, m.y, P->nb);
+}
+
+// One block per pair: identity state, zero sums before iteration 0 and zero
+// delta rows for `iters` iterations.
+__global__ __launch_bounds__(64) void batch_reset_kernel(const BatchPair *__restrict__ pairs, int iters)
+{
+    const BatchPair *P = pairs + blockIdx.x;
+    IcpState *st = P->st;
+    const int t = threadIdx.x;
+    if (t < 9) st->R[t] = (t % 4 == 0) ? 1.0 : 0.0;
+    if (t < 3) st->T[t] = 0.0;
+    if (t < 16) st->Trans[t] = (t % 5 == 0) ? 1.0 : 0.0;
+    if (t < kNumSums) { st->S[t] = 0.0; P->totals[t] = 0.0; }
+    if (t == 0) st->status = 0;
+    for (int k = t; k < iters * kNumSums; k += 64) P->deltas[k] = 0.0;
+}
+
+// One wave per pair: the last iteration's solve.
+__global__ __launch_bounds__(64) void batch_solve_kernel(const BatchPair *__restrict__ pairs, int iter)
+{
+    __shared__ double rt[12];
+    const BatchPair *P = pairs + blockIdx.x;
+    solve_and_update(P->totals + (size_t)iter * kNumSums, P->deltas + (size_t)iter * kNumSums,
+                     P->totals + (size_t)(iter + 1) * kNumSums, P->st, P->X_hist, P->info_hist, iter,
+                     true, rt);
+}
+
+// Gathers every pair's state into one array for a single copy to the host.
+__global__ void batch_collect_kernel(const BatchPair *__restrict__ pairs, int count,
+                                     IcpState *__restrict__ out)
+{
+    constexpr int W = sizeof(IcpState) / sizeof(double);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)count * W) return;
+    const int p = (int)(i / W), w = (int)(i % W);
+    reinterpret_cast<double *>(out + p)[w] = reinterpret_cast<const double *>(pairs[p].st)[w];
 }
 
 // One wave: solve the system of iteration `iter` and record the result (the

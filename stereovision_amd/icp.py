@@ -188,6 +188,49 @@ class Context:
         return ms.value
 
 
+class Batch:
+    """Many independent pairs advanced together, one kernel launch per iteration
+    (svicp_batch_* of include/svicp.h).  `contexts` already hold target and source."""
+
+    def __init__(self, contexts):
+        self._lib = _lib.load()
+        self.contexts = list(contexts)
+        arr = (C.c_void_p * len(self.contexts))(*[c._h for c in self.contexts])
+        self._h = C.c_void_p()
+        rc = self._lib.svicp_batch_create(arr, len(self.contexts), C.byref(self._h))
+        if rc != 0:
+            msg = self.contexts[0]._lib.svicp_last_error(self.contexts[0]._h) if self.contexts else b""
+            raise SvicpError(rc, (msg or b"").decode())
+
+    def run(self, iterations):
+        """Returns (count x 4 x 4 transforms, list of Info)."""
+        n = len(self.contexts)
+        T = np.empty((n, 16), np.float64)
+        infos = (Info * n)()
+        rc = self._lib.svicp_batch_run(self._h, int(iterations), _dp(T), infos)
+        for c in self.contexts:
+            c._iters = int(iterations)
+        if rc != 0:
+            raise SvicpError(rc, self._lib.svicp_batch_last_error(self._h).decode())
+        return T.reshape(n, 4, 4), list(infos)
+
+    def last_ms(self):
+        ms = C.c_double()
+        self._lib.svicp_batch_last_ms(self._h, C.byref(ms))
+        return ms.value
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.svicp_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class CKNNSearch:
     """CKNNSearch (CKNNSearch.h:9-25): exact k-NN, squared fp32 distances."""
 

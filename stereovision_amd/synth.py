@@ -98,6 +98,19 @@ def make_pair(side, pair=0, pose=None):
     return tgt.astype(np.float32), nrm.astype(np.float32), src.astype(np.float32), P
 
 
+SEED_POSE = 0x5EED0004
+
+
+def small_pose(pair):
+    """A per-pair random small pose: angles within +-0.8 degrees, shift within +-1.2."""
+    u = uniform01(SEED_POSE, 6 * pair, 6) * 2.0 - 1.0
+    d = np.pi / 180.0
+    P = np.eye(4)
+    P[:3, :3] = rot_zyx(0.8 * d * u[0], 0.8 * d * u[1], 0.8 * d * u[2])
+    P[:3, 3] = 1.2 * u[3:]
+    return P
+
+
 SEED_CALIB = 0x5EED0005
 
 

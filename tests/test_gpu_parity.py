@@ -341,3 +341,86 @@ def test_exact_and_capped_search_agree_within_threshold(ctx, po):
     hit = od[:, 0] <= 5.0
     assert np.array_equal(capped_i[hit], oi[hit, 0]) and (capped_i[~hit] == -1).all()
     assert ctx.time_nn(exact=True, reps=2) > 0 and ctx.time_nn(exact=False, reps=2) > 0
+
+
+# ---- batches of independent pairs ---------------------------------------------
+def _batch_pairs():
+    """Pairs of different sizes (ragged last tiles, fewer points than one tile) and poses."""
+    from stereovision_amd import synth
+    out = []
+    for i, (side, cut) in enumerate([(64, 0), (48, 7), (96, 1000), (20, 0), (64, 3), (33, 0)]):
+        tgt, nrm, src, _ = synth.make_pair(side, pair=i, pose=synth.small_pose(i))
+        out.append((tgt, nrm, np.ascontiguousarray(src[: len(src) - cut])))
+    return out
+
+
+@pytest.mark.parametrize("coherent", [1, 0])
+def test_batch_equals_one_by_one(po, coherent):
+    import stereovision_amd as sv
+    pairs = _batch_pairs()
+    singles, ctxs = [], []
+    for tgt, nrm, src in pairs:
+        c = sv.Context(0, coherent=coherent)
+        c.set_target(tgt, nrm)
+        c.set_source(src)
+        T, info = c.run(8)
+        singles.append((T, info.inliers, c.history()[0], c.get_source()))
+        c.set_source(src)              # back to the start for the batch
+        ctxs.append(c)
+    batch = sv.Batch(ctxs)
+    for _ in range(2):                 # the second run replays the captured graph
+        Ts, infos = batch.run(8)
+        for i, c in enumerate(ctxs):
+            T, inl, X, moved = singles[i]
+            assert np.abs(Ts[i] - T).max() < 1e-10
+            assert infos[i].inliers == inl and infos[i].iterations == 8
+            assert np.abs(c.history()[0] - X).max() < 1e-10
+            assert np.abs(c.get_source() - moved).max() <= 4e-5
+    # and against the oracle for one of them
+    tgt, nrm, src = pairs[2]
+    r = po.icp_point2plane(po.KDTree(tgt), nrm, src, 8)
+    assert np.abs(Ts[2] - r["trans"]).max() < 1e-6 * max(1.0, np.abs(r["trans"]).max())
+    batch.close()
+
+
+def test_batch_argument_errors():
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+    tgt, nrm, src, _ = synth.make_pair(16)
+    a, b = sv.Context(0), sv.Context(0)
+    a.set_target(tgt, nrm)
+    a.set_source(src)
+    with pytest.raises(sv.SvicpError):
+        sv.Batch([a, b])               # b holds nothing
+    with pytest.raises(sv.SvicpError):
+        sv.Batch([a, a])
+    with pytest.raises(sv.SvicpError):
+        sv.Batch([a]).run(0)
+
+
+def test_batch_many_small_pairs_throughput_property():
+    """64 pairs of 128^2 points: every pair converges to its own pose, and the batch does
+    the work of 64 single runs."""
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+    ctxs, poses = [], []
+    for i in range(64):
+        tgt, nrm, src, pose = synth.make_pair(128, pair=i, pose=synth.small_pose(i))
+        c = sv.Context(0)
+        c.set_target(tgt, nrm)
+        c.set_source(src)
+        ctxs.append(c)
+        poses.append(pose)
+    batch = sv.Batch(ctxs)
+    Ts, infos = batch.run(30)
+    for i in range(64):
+        assert infos[i].status == 0 and infos[i].inliers > 0.9 * 128 * 128
+        assert infos[i].step_norm < 1e-3
+    # the recovered motion undoes the pose the source was moved by
+    for i in (0, 17, 63):
+        M = Ts[i] @ poses[i]
+        assert refmath.rot_angle(M[:3, :3], np.eye(3)) < 2e-3 and np.abs(M[:3, 3]).max() < 0.5
+    ctxs[5].set_source(synth.make_pair(128, pair=5, pose=synth.small_pose(5))[2])
+    T0, _ = ctxs[5].run(30)
+    assert np.abs(T0 - Ts[5]).max() < 1e-10
+    print(f"batch of 64 x 16384 points, 30 iterations: {batch.last_ms():.3f} ms")
