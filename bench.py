@@ -37,6 +37,8 @@ def parse():
                     help="side of the pair of the sharded leg; 0 disables the leg")
     ap.add_argument("--cpu-iters", type=int, default=30,
                     help="iterations of the CPU baseline sample; 0 disables it")
+    ap.add_argument("--batch-pairs", type=int, default=64,
+                    help="pairs (256^2 points each) per rank of the batched leg; 0 disables it")
     ap.add_argument("--cal-views", type=int, default=2000,
                     help="views of the calibration leg (11 x 8 board each); 0 disables the leg")
     return ap.parse_args()
@@ -165,6 +167,43 @@ def main():
         }
         sctx.close()
 
+    # ---- batched leg: many small independent pairs per rank, one launch per
+    # iteration for all of them; ranks take disjoint pairs, no collective ----
+    batched = None
+    if args.batch_pairs > 0:
+        bctx = []
+        for i in range(args.batch_pairs):
+            pid = rank * args.batch_pairs + i
+            bt, bn, bs, _ = synth.make_pair(256, pair=pid, pose=synth.small_pose(pid))
+            c = sv.Context(local)
+            c.set_target(bt, bn)
+            c.set_source(bs)
+            bctx.append(c)
+        batch = sv.Batch(bctx)
+        batch.run(args.iters)
+        barrier()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            batch.run(args.iters)
+        barrier()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        batched = {
+            "workload": f"{args.batch_pairs} independent pairs of 65536 points per rank, "
+                        f"{args.iters} iterations, per-pair pose, one launch per iteration",
+            "pair_iterations_per_s": world * reps * args.batch_pairs * args.iters / dt,
+            "point_iterations_per_s": world * reps * args.batch_pairs * args.iters * 65536 / dt,
+            "device_ms_per_run": batch.last_ms(),
+            "scaling": "weak",
+        }
+        batch.close()
+        for c in bctx:
+            c.close()
+
     # ---- calibration leg: residual + Jacobian evaluations of the stereo refinement,
     # views split over the ranks, one 272-double all-reduce per evaluation ----
     calibration = None
@@ -276,6 +315,7 @@ def main():
             "grid_build_ms": grid_build_s * 1e3,
             "final_step_norm": info.step_norm,
             "sharded": sharded,
+            "batched": batched,
             "calibration": calibration,
         }
         print(json.dumps(out))

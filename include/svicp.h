@@ -174,6 +174,27 @@ int svicp_shard_update(svicp_ctx *ctx, const double *dev_sum32);
 /* Solves the last iteration's system and copies out the accumulated transform. */
 int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info);
 
+/* ---- point-to-point variant -------------------------------------------- */
+
+/* CPoint2PointICP::run (CPoint2PointICP.cpp:50-81) on the same context: per
+ * iteration 1-NN, the weight function of :94-103 with options.dist_threshold
+ * as its cut-off (the reference hard-codes 15.0 at :90; set it BEFORE
+ * svicp_set_target, it sizes the grid), strict "<" selection (:106), weighted
+ * centroids, fp32-centred cross-covariance divided by the selected count
+ * (:128-147), R = V diag(1, 1, det) U^T from its SVD and T = ref centroid -
+ * R * move centroid (:149-158).  Normals are not used: pass any m x 3 array
+ * as normals to svicp_set_target to skip their estimation.  The centroid sums
+ * are accumulated in fp64 (the reference: fp32 in point order).
+ * info: inliers = selected count, weighted_sq_residual = sum w d^2,
+ * step_norm = sqrt(angle^2 + |T|^2) of the last increment.
+ * Returns SVICP_ERR_SINGULAR if an iteration selected no point. */
+int svicp_run_point2point(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info);
+
+/* Per-iteration increments of the last svicp_run_point2point: RT_out
+ * iterations x 12 {R row-major, T}; info_out iterations x 4 {selected count,
+ * sum w d^2, step norm, sum w}.  Either pointer may be NULL. */
+int svicp_get_history_rt(svicp_ctx *ctx, double *RT_out, double *info_out);
+
 /* ---- batches of independent pairs (one launch per iteration for all) ---- */
 /* Many small registrations do not fill the GPU one at a time.  A batch takes
  * contexts that already hold their target and source (all on one device) and

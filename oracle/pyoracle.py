@@ -15,7 +15,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("icp_oracle.c", "cal_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("icp_oracle.c", "cal_oracle.c", "p2p_oracle.c")]
     if force or not os.path.exists(so) or any(
         os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so) for src in srcs
     ):
@@ -219,3 +219,46 @@ def mono_residual_jacobian_dense(vec, world, img, want_jacobian=True):
     _cal_lib().orc_mono_residual_jacobian_dense(_d(vec), V, Cn, _d(world), _d(img), _d(res),
                                                 _d(J) if want_jacobian else None)
     return res, J
+
+
+# ---------------------------------------------------------------- point-to-point ICP
+def kabsch_rotation(W):
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.orc_kabsch_rotation.argtypes = [dp, dp]
+    W = _dd(W).reshape(9)
+    R = np.empty(9)
+    L.orc_kabsch_rotation(_d(W), _d(R))
+    return R.reshape(3, 3)
+
+
+def svd3(W):
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.orc_svd3.argtypes = [dp, dp, dp, dp]
+    W = _dd(W).reshape(9)
+    U, S, V = np.empty(9), np.empty(3), np.empty(9)
+    L.orc_svd3(_d(W), _d(U), _d(S), _d(V))
+    return U.reshape(3, 3), S, V.reshape(3, 3)
+
+
+def icp_point2point(tree, src, iters, faithful=True, threads=1, history=True):
+    """Runs the restated CPoint2PointICP::run; src is copied, the updated copy is returned."""
+    L = lib()
+    fp, ip, dp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    L.orc_icp_point2point.restype = C.c_int
+    L.orc_icp_point2point.argtypes = [C.c_void_p, fp, fp, C.c_int64, C.c_int, dp, dp, dp, ip, fp,
+                                      dp, C.c_int, C.c_int]
+    src = _cloud(src).copy()
+    n = src.shape[0]
+    trans = np.empty(16, np.float64)
+    RT = np.empty((iters, 12), np.float64)
+    W = np.empty((iters, 9), np.float64)
+    info = np.empty((iters, 4), np.float64)
+    idx = np.empty((iters, n), np.int32) if history else None
+    d2 = np.empty((iters, n), np.float32) if history else None
+    rc = L.orc_icp_point2point(tree._h, _f(tree.ref), _f(src), n, iters, _d(trans), _d(RT), _d(W),
+                               _i(idx) if history else None, _f(d2) if history else None,
+                               _d(info), 1 if faithful else 0, threads)
+    return dict(rc=rc, trans=trans.reshape(4, 4), RT=RT, W=W.reshape(iters, 3, 3), info=info,
+                idx=idx, d2=d2, src=src)

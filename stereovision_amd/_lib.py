@@ -70,6 +70,8 @@ SYMBOLS = {
     "svicp_iteration_times": (C.c_int, [_ctx, _dp, _dp]),
     "svicp_time_nn": (C.c_int, [_ctx, C.c_int, C.c_int, _dp]),
     "svicp_sizes": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "svicp_run_point2point": (C.c_int, [_ctx, C.c_int, _dp, C.POINTER(Info)]),
+    "svicp_get_history_rt": (C.c_int, [_ctx, _dp, _dp]),
     "svicp_batch_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.POINTER(C.c_void_p)]),
     "svicp_batch_destroy": (C.c_int, [C.c_void_p]),
     "svicp_batch_last_error": (C.c_char_p, [C.c_void_p]),

@@ -15,6 +15,7 @@
 
 #include "svicp.h"
 #include "svicp_device.hpp"
+#include "svicp_p2p.hpp"
 
 using namespace svicp;
 
@@ -80,6 +81,12 @@ struct svicp_ctx {
     int timed_launches = 0;
 
     int shard_iter = 0;
+
+    // point-to-point variant
+    DevBuf p2p_sums, rthist;
+    hipGraphExec_t gexec_p2p = nullptr;
+    int g_iters_p2p = -1;
+    bool last_was_p2p = false;
 };
 
 
@@ -127,6 +134,8 @@ void drop_graph(svicp_ctx *ctx)
 {
     if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
     ctx->g_iters = -1;
+    if (ctx->gexec_p2p) { (void)hipGraphExecDestroy(ctx->gexec_p2p); ctx->gexec_p2p = nullptr; }
+    ctx->g_iters_p2p = -1;
 }
 
 // bounding box of an n x 3 device array; returns through mn/mx
@@ -747,6 +756,7 @@ int svicp_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->cur = iterations > 1 ? 1 : 0;
     ctx->last_iters = iterations;
+    ctx->last_was_p2p = false;
     std::memcpy(T_out, ctx->h_state->Trans, sizeof(double) * 16);
     fill_info(ctx, iterations, info);
 
@@ -941,6 +951,103 @@ int svicp_time_nn(svicp_ctx *ctx, int exact, int reps, double *avg_ms)
     return SVICP_OK;
 }
 
+/* ---- point-to-point variant --------------------------------------------- */
+
+int svicp_run_point2point(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (iterations < 1 || !T_out)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_run_point2point: iterations must be >= 1 and T_out non-NULL");
+    if (!ctx->have_target || !ctx->have_source)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_run_point2point: set the target and the source first");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_iteration_buffers(ctx, iterations);
+    if (rc) return rc;
+    {
+        void *a = ctx->p2p_sums.p, *b = ctx->rthist.p;
+        HIPCHK(ctx->p2p_sums.reserve(sizeof(double) * kNumSums * ctx->hist_cap));
+        HIPCHK(ctx->rthist.reserve(sizeof(double) * 12 * ctx->hist_cap));
+        if (a != ctx->p2p_sums.p || b != ctx->rthist.p) drop_graph(ctx);
+    }
+    const int n = (int)ctx->n;
+    const int nb = std::max(1, cdiv(std::max(n, 1), kP2PTile));
+    auto enqueue = [&]() -> int {
+        float *wx = ctx->wx.as<float>(), *wy = ctx->wy.as<float>(), *wz = ctx->wz.as<float>();
+        const float *x0 = ctx->sx0.as<float>(), *y0 = ctx->sy0.as<float>(), *z0 = ctx->sz0.as<float>();
+        IcpState *state = ctx->state.as<IcpState>();
+        double *sums = ctx->p2p_sums.as<double>();
+        float4 *tp = ctx->st_tp.as<float4>();
+        const float thr = ctx->opt.dist_threshold;
+        hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(64), 0, ctx->stream, state);
+        LAUNCHCHK("reset_state_kernel");
+        HIPCHK(hipMemsetAsync(sums, 0, sizeof(double) * kNumSums * iterations, ctx->stream));
+        for (int k = 0; k < iterations; ++k) {
+            double *sk = sums + (size_t)k * kNumSums;
+            const float *cx = k <= 1 ? x0 : wx, *cy = k <= 1 ? y0 : wy, *cz = k <= 1 ? z0 : wz;
+            if (k == 0)
+                hipLaunchKernelGGL((p2p_match_kernel<false>), dim3(nb), dim3(256), 0, ctx->stream,
+                                   ctx->g, cx, cy, cz, wx, wy, wz, n, state, thr, tp, sk);
+            else
+                hipLaunchKernelGGL((p2p_match_kernel<true>), dim3(nb), dim3(256), 0, ctx->stream,
+                                   ctx->g, cx, cy, cz, wx, wy, wz, n, state, thr, tp, sk);
+            LAUNCHCHK("p2p_match_kernel");
+            // the covariance is taken about the positions the match used
+            const float *px = k == 0 ? x0 : wx, *py = k == 0 ? y0 : wy, *pz = k == 0 ? z0 : wz;
+            hipLaunchKernelGGL(p2p_cov_kernel, dim3(nb), dim3(256), 0, ctx->stream, px, py, pz, n, tp, sk);
+            LAUNCHCHK("p2p_cov_kernel");
+            hipLaunchKernelGGL(p2p_solve_kernel, dim3(1), dim3(64), 0, ctx->stream, sk, state,
+                               ctx->rthist.as<double>(), ctx->ihist.as<double>(), k);
+            LAUNCHCHK("p2p_solve_kernel");
+        }
+        return SVICP_OK;
+    };
+    if (ctx->opt.use_graph) {
+        if (!ctx->gexec_p2p || ctx->g_iters_p2p != iterations) {
+            if (ctx->gexec_p2p) { (void)hipGraphExecDestroy(ctx->gexec_p2p); ctx->gexec_p2p = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue();
+            hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (e != hipSuccess) return fail(ctx, SVICP_ERR_HIP, "hipStreamEndCapture", e);
+            e = hipGraphInstantiate(&ctx->gexec_p2p, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { ctx->gexec_p2p = nullptr; return fail(ctx, SVICP_ERR_HIP, "hipGraphInstantiate", e); }
+            ctx->g_iters_p2p = iterations;
+        }
+        HIPCHK(hipGraphLaunch(ctx->gexec_p2p, ctx->stream));
+    } else {
+        rc = enqueue();
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->state.p, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->cur = iterations > 1 ? 1 : 0;
+    ctx->last_iters = iterations;
+    ctx->last_was_p2p = true;
+    std::memcpy(T_out, ctx->h_state->Trans, sizeof(double) * 16);
+    fill_info(ctx, iterations, info);
+    if (ctx->h_state->status == SVICP_ERR_SINGULAR)
+        return fail(ctx, SVICP_ERR_SINGULAR, "svicp_run_point2point: no point had a neighbour within the threshold");
+    return SVICP_OK;
+}
+
+int svicp_get_history_rt(svicp_ctx *ctx, double *RT_out, double *info_out)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (ctx->last_iters <= 0 || !ctx->last_was_p2p)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_get_history_rt: no point-to-point run yet");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (RT_out)
+        HIPCHK(hipMemcpyAsync(RT_out, ctx->rthist.p, sizeof(double) * 12 * ctx->last_iters,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    if (info_out)
+        HIPCHK(hipMemcpyAsync(info_out, ctx->ihist.p, sizeof(double) * 4 * ctx->last_iters,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SVICP_OK;
+}
+
 /* ---- batches of independent pairs -------------------------------------- */
 
 int svicp_batch_create(svicp_ctx **ctxs, int count, svicp_batch **out)
@@ -1090,6 +1197,7 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
         *c->h_state = b->h_states[i];
         c->cur = iterations > 1 ? 1 : 0;
         c->last_iters = iterations;
+        c->last_was_p2p = false;
         std::memcpy(T_out + 16 * (size_t)i, c->h_state->Trans, sizeof(double) * 16);
         if (info_out) fill_info(c, iterations, info_out + i);
         if (c->h_state->status == SVICP_ERR_SINGULAR) worst = SVICP_ERR_SINGULAR;

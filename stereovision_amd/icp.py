@@ -122,6 +122,23 @@ class Context:
         self._check(self._lib.svicp_run(self._h, int(iterations), _dp(T), C.byref(info)))
         return T.reshape(4, 4), info
 
+    def run_point2point(self, iterations):
+        """CPoint2PointICP::run on this context.  Returns (4x4 transform, Info)."""
+        T = np.empty(16, np.float64)
+        info = Info()
+        self._iters = int(iterations)
+        self._check(self._lib.svicp_run_point2point(self._h, int(iterations), _dp(T), C.byref(info)))
+        return T.reshape(4, 4), info
+
+    def history_rt(self):
+        """Per-iteration {R, T} (iters x 12) and {count, sum w d2, step, sum w} (iters x 4)
+        of the last point-to-point run."""
+        iters = getattr(self, "_iters", 0)
+        RT = np.empty((iters, 12), np.float64)
+        I = np.empty((iters, 4), np.float64)
+        self._check(self._lib.svicp_get_history_rt(self._h, _dp(RT), _dp(I)))
+        return RT, I
+
     def history(self):
         """Per-iteration X (iters x 6) and {inliers, sum w b^2, |X|, sum w} (iters x 4)."""
         iters = getattr(self, "_iters", 0)
@@ -307,6 +324,29 @@ class CPoint2PlaneICP:
 
     def getNormals(self):
         return self._ctx.get_normals()
+
+
+class CPoint2PointICP(CPoint2PlaneICP):
+    """CPoint2PointICP (CPoint2PointICP.h:8-27): same surface as CPoint2PlaneICP; the
+    threshold of its weight function is 15 (CPoint2PointICP.cpp:90) and no normals are used."""
+
+    def __init__(self, device=0, verbose=True):
+        super().__init__(device, verbose)
+        self._ctx.set_options(dist_threshold=15.0)
+
+    def setReferenceData(self, ref, normals=None):
+        ref = _cloud(ref, "ref")
+        self._ctx.set_target(ref, ref)      # the second argument only suppresses normal estimation
+
+    def run(self):
+        if self._move is None:
+            raise SvicpError(_lib.ERR_ARG, "run: setMoveData was not called")
+        self._ctx.set_source(self._move)
+        self._T, self._info = self._ctx.run_point2point(self.m_count)
+        self._ctx.get_source(self._move)
+        if self._verbose:
+            print("Current Transformation:")
+            print(self._T)
 
 
 class CTxtReader:

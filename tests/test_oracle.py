@@ -149,3 +149,72 @@ def test_empty_source_is_singular(po, synth32):
     tgt, nrm = synth32["target"], synth32["normals"]
     r = po.icp_point2plane(po.KDTree(tgt), nrm, np.zeros((0, 3), np.float32), 1)
     assert r["rc"] != 0 and np.isnan(r["X"]).all()
+
+
+# ---- point-to-point ICP (CPoint2PointICP.cpp) -----------------------------------
+def test_svd3_and_kabsch_against_numpy(po):
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        W = rng.normal(size=(3, 3)) * rng.uniform(0.1, 100)
+        if trial % 3 == 0:
+            W[:, 2] *= 1e-6
+        U, S, V = po.svd3(W)
+        assert np.allclose(U @ np.diag(S) @ V.T, W, atol=1e-12 * np.abs(W).max())
+        assert np.allclose(V.T @ V, np.eye(3), atol=1e-12) and np.all(np.diff(S) <= 0)
+        u, s, vt = np.linalg.svd(W)
+        assert np.allclose(S, s, rtol=1e-10)
+        D = np.diag([1, 1, np.sign(np.linalg.det(vt.T @ u.T))])
+        assert np.allclose(po.kabsch_rotation(W), vt.T @ D @ u.T, atol=1e-8)
+
+
+def _p2p_single_numpy(ref, src, idx, d2, thr=15.0):
+    """One CPoint2PointICP::singleRun (:83-159) in numpy, centroid sums in fp64."""
+    F = np.float32
+    d2 = d2.astype(F)
+    sl = (d2 / F(thr)).astype(F)
+    ss = (sl * sl).astype(F)
+    w = ((1.0 - ss.astype(np.float64)) ** 2).astype(F)
+    sel = d2 < F(thr)
+    w, mv, rf = w[sel], src[sel].astype(F), ref[idx[sel]].astype(F)
+    sw = w.astype(np.float64).sum()
+    mu_m = ((mv * w[:, None]).astype(F).astype(np.float64).sum(0) / sw).astype(F)
+    mu_r = ((rf * w[:, None]).astype(F).astype(np.float64).sum(0) / sw).astype(F)
+    mc, rc = (mv - mu_m).astype(F), (rf - mu_r).astype(F)
+    count = F(sel.sum())
+    W = np.zeros((3, 3))
+    for j in range(3):
+        for i in range(3):
+            prod = (mc[:, j] * rc[:, i]).astype(F)
+            W[j, i] = ((w * prod).astype(F) / count).astype(F).astype(np.float64).sum()
+    u, s, vt = np.linalg.svd(W)
+    D = np.diag([1, 1, np.sign(np.linalg.det(vt.T @ u.T))])
+    R = vt.T @ D @ u.T
+    T = mu_r.astype(np.float64) - R @ mu_m.astype(np.float64)
+    return R, T, W, int(sel.sum())
+
+
+def test_point2point_first_iteration_against_numpy(po, pair):
+    ref, src, _ = pair
+    tree = po.KDTree(ref)
+    r = po.icp_point2point(tree, src, 1, faithful=False)
+    R, T, W, count = _p2p_single_numpy(ref, src, r["idx"][0], r["d2"][0])
+    assert r["info"][0, 0] == count
+    assert np.allclose(r["W"][0], W, rtol=1e-12, atol=1e-12 * np.abs(W).max())
+    assert np.allclose(r["RT"][0, :9].reshape(3, 3), R, atol=1e-10)
+    assert np.allclose(r["RT"][0, 9:], T, atol=1e-8)
+
+
+def test_point2point_registers_the_bundled_pair(po, pair):
+    """17.txt is 15.txt moved rigidly: five iterations bring the weighted squared distance to
+    (almost) zero.  The fp32 running sums of the reference (faithful) and fp64 sums differ in
+    the fifth digit of the translation."""
+    ref, src, _ = pair
+    tree = po.KDTree(ref)
+    a = po.icp_point2point(tree, src, 5, faithful=True)
+    b = po.icp_point2point(tree, src, 5, faithful=False)
+    assert a["rc"] == 0 and b["rc"] == 0
+    assert a["info"][-1, 0] == len(src) and a["info"][-1, 2] < 1e-2 and b["info"][-1, 2] < 1e-2
+    assert np.abs(a["trans"] - b["trans"]).max() < 1e-4
+    assert refmath.rot_angle(a["trans"][:3, :3], b["trans"][:3, :3]) < 1e-6
+    d = np.abs(a["src"] - ref[a["idx"][-1]]).max()
+    assert d < 1e-2
