@@ -176,28 +176,72 @@ def assemble_dense(blocks, k, V, stereo=True):
     return A, G
 
 
-def lm_refine(evaluator, params, k=5, max_iter=100, verbose=False):
+def solve_damped(blocks, k, V, lam, stereo=True):
+    """step = -(A + lam diag(A))^-1 G without forming A: the per-view 6 x 6 blocks are
+    eliminated first (Schur complement), which leaves a system in the 2 (4 + k) + 6 shared
+    parameters (4 + k monocular).  Equal to the dense solve of the reference
+    (CStereoCameraCalibration.cpp:288-291) up to rounding, at O(V) cost instead of O(V^3).
+    Returns (step in the reference's parameter order, step^T (lam step - G))."""
+    nI = 4 + k
+    nC = 2 * nI + 6 if stereo else nI
+    Acc, gc = np.zeros((nC, nC)), np.zeros(nC)
+    Acc[:nI, :nI] = blocks["LL"]
+    gc[:nI] = blocks["gL"]
+    if stereo:
+        Acc[nI:2 * nI, nI:2 * nI] = blocks["RR"]
+        Acc[nI:2 * nI, 2 * nI:] = blocks["RS"]
+        Acc[2 * nI:, nI:2 * nI] = blocks["RS"].T
+        Acc[2 * nI:, 2 * nI:] = blocks["SS"]
+        gc[nI:2 * nI], gc[2 * nI:] = blocks["gR"], blocks["gS"]
+    Acc = Acc + lam * np.diag(np.diag(Acc))
+    EE = blocks["EE"] + lam * np.einsum("vij,ij->vij", blocks["EE"], np.eye(6))
+    LE, gE = blocks["LE"], blocks["gE"]                         # (V, nI, 6), (V, 6)
+    Einv_LEt = np.linalg.solve(EE, np.transpose(LE, (0, 2, 1)))  # (V, 6, nI)
+    Einv_g = np.linalg.solve(EE, gE[:, :, None])[:, :, 0]        # (V, 6)
+    S = Acc.copy()
+    S[:nI, :nI] -= np.einsum("vaq,vqb->ab", LE, Einv_LEt)
+    rhs = gc.copy()
+    rhs[:nI] -= np.einsum("vaq,vq->a", LE, Einv_g)
+    dc = -np.linalg.solve(S, rhs)
+    de = -(Einv_g + np.einsum("vqa,a->vq", Einv_LEt, dc[:nI]))
+    if stereo:
+        step = np.concatenate([dc[:2 * nI], de.ravel(), dc[2 * nI:]])
+        G = np.concatenate([gc[:2 * nI], gE.ravel(), gc[2 * nI:]])
+    else:
+        step = np.concatenate([dc, de.ravel()])
+        G = np.concatenate([gc, gE.ravel()])
+    return step, float(step @ (lam * step - G))
+
+
+def lm_refine(evaluator, params, k=5, max_iter=100, verbose=False, dense=False):
     """The reference's damped Gauss-Newton loop (CStereoCameraCalibration.cpp:278-335):
     lambda0 = 1e-3, A + lambda diag(A), gain-ratio update, stops on |step| < 1e-5,
-    |e| < 1e-3 or 100 iterations.  Dense solve on the host: for small V."""
+    |e| < 1e-3 or 100 iterations.  One device evaluation per trial step; the linear solve
+    runs on the host, block-sparse (solve_damped) unless dense=True (small V only)."""
     x = np.array(params, np.float64)
     V, stereo = evaluator.V, evaluator.stereo
+
+    def solve(b, lam):
+        if dense:
+            A, G = assemble_dense(b, k, V, stereo)
+            step = -np.linalg.solve(A + lam * np.diag(np.diag(A)), G)
+            return step, float(step @ (lam * step - G))
+        return solve_damped(b, k, V, lam, stereo)
+
     b = evaluator.evaluate(x, k, want_residual=False)
-    A, G = assemble_dense(b, k, V, stereo)
     err2 = b["sq_residual"]
     lam, v = 1.0e-3, 2.0
     for it in range(max_iter):
-        step = -np.linalg.solve(A + lam * np.diag(np.diag(A)), G)
+        step, denom = solve(b, lam)
         if np.linalg.norm(step) < 1.0e-5:
             break
         nb = evaluator.evaluate(x + step, k, want_residual=False)
-        r = (err2 - nb["sq_residual"]) / float(step @ (lam * step - G))
+        r = (err2 - nb["sq_residual"]) / denom
         if verbose:
             print(f"iter {it}: |e| {np.sqrt(err2):.6g} -> {np.sqrt(nb['sq_residual']):.6g}, gain {r:.3g}")
         if r > 0:
             x = x + step
-            A, G = assemble_dense(nb, k, V, stereo)
-            err2 = nb["sq_residual"]
+            b, err2 = nb, nb["sq_residual"]
             if np.sqrt(err2) < 1.0e-3:
                 break
             lam *= max(1.0 / 3.0, 1.0 - (2.0 * r - 1.0) ** 3)

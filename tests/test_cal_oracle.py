@@ -111,3 +111,29 @@ def test_mono_on_reference_corners(po, corners):
         x = x - np.linalg.solve(A + 1e-3 * np.diag(np.diag(A)), J.T @ res)
     res, _ = po.mono_residual_jacobian_dense(x, world, img, want_jacobian=False)
     assert np.sqrt((res ** 2).mean()) < 1.0
+
+
+def test_block_sparse_solve_equals_dense_solve(po):
+    """The damped step with the per-view blocks eliminated first equals the reference's dense
+    (A + lambda diag A)^-1 G (CStereoCameraCalibration.cpp:288-291)."""
+    from stereovision_amd.calib import solve_damped
+    for V in (1, 6):
+        w, l, r, _, start = synth.make_stereo_views(views=V)
+        b = po.stereo_eval_sparse(start, 5, w, l, r, False)
+        A, G = assemble_dense(b, 5, V)
+        for lam in (1e-3, 0.5):
+            ref = -np.linalg.solve(A + lam * np.diag(np.diag(A)), G)
+            step, denom = solve_damped(b, 5, V, lam)
+            assert np.abs(step - ref).max() < 1e-10 * np.abs(ref).max()
+            assert denom == pytest.approx(ref @ (lam * ref - G), rel=1e-10)
+    # monocular layout
+    c = np.load(os.path.join(GOLD, "testdata_corners.npz"))
+    x0 = homography_start(c["world_mono"], c["mono"], (1920, 1080))
+    res, J = po.mono_residual_jacobian_dense(x0, c["world_mono"], c["mono"])
+    A, G = J.T @ J, J.T @ res
+    blocks = dict(LL=A[:9, :9], gL=G[:9], LE=np.stack([A[:9, 9 + 6 * v:15 + 6 * v] for v in range(4)]),
+                  EE=np.stack([A[9 + 6 * v:15 + 6 * v, 9 + 6 * v:15 + 6 * v] for v in range(4)]),
+                  gE=G[9:].reshape(4, 6))
+    step, _ = solve_damped(blocks, 5, 4, 1e-3, stereo=False)
+    ref = -np.linalg.solve(A + 1e-3 * np.diag(np.diag(A)), G)
+    assert np.abs(step - ref).max() < 1e-9 * np.abs(ref).max()
