@@ -91,6 +91,12 @@ def load():
                 f"{LIB_PATH} is missing: build it with `make -C stereovision_amd/csrc` "
                 "(hipcc, --offload-arch=gfx950). There is no CPU fallback."
             )
+        # A process that also uses PyTorch must load PyTorch's bundled HIP runtime before
+        # this library pulls in the system one: with the other order torch finds no GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)   # AttributeError if the export is missing

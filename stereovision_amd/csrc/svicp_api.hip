@@ -68,7 +68,8 @@ struct svicp_ctx {
 
     // iteration loop
     DevBuf partials, totals, deltas, state, xhist, ihist;
-    IcpState *h_state = nullptr;   // pinned
+    IcpState *h_state = nullptr;   // pinned and mapped: the kernel that ends a run writes it
+    IcpState *h_state_dev = nullptr;
     int hist_cap = 0, last_iters = 0;
     int nb = 0, chunk = 0;
     hipGraphExec_t gexec = nullptr;
@@ -261,10 +262,17 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
         HIPCHK(ctx->xhist.reserve(sizeof(double) * 6 * cap));
         HIPCHK(ctx->ihist.reserve(sizeof(double) * 4 * cap));
         HIPCHK(ctx->totals.reserve(sizeof(double) * kNumSums * (cap + 1)));
-        HIPCHK(ctx->deltas.reserve(sizeof(double) * kNumSums * cap));
+        HIPCHK(ctx->deltas.reserve(sizeof(double) * kNumSums * (cap + 1)));
+        // totals row 0 (the sums "before iteration 0") stays zero for good; delta rows are
+        // cleared by the kernels themselves from here on
+        HIPCHK(hipMemsetAsync(ctx->totals.p, 0, sizeof(double) * kNumSums * (cap + 1), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->deltas.p, 0, sizeof(double) * kNumSums * (cap + 1), ctx->stream));
         ctx->hist_cap = cap;
     }
-    if (!ctx->h_state) HIPCHK(hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState), 0));
+    if (!ctx->h_state) {
+        HIPCHK(hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void **)&ctx->h_state_dev, ctx->h_state, 0));
+    }
     return SVICP_OK;
 }
 
@@ -306,12 +314,9 @@ void launch_iteration(svicp_ctx *ctx, int k, double *partials)
 
 int enqueue_loop(svicp_ctx *ctx, int iters, bool timed)
 {
-    hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(64), 0, ctx->stream,
-                       ctx->state.as<IcpState>());
-    LAUNCHCHK("reset_state_kernel");
-    // totals row 0 (the sums "before iteration 0") and every delta row start at zero
-    HIPCHK(hipMemsetAsync(ctx->totals.p, 0, sizeof(double) * kNumSums, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->deltas.p, 0, sizeof(double) * kNumSums * iters, ctx->stream));
+    // no reset and no clearing here: the first solve of a run starts the state afresh,
+    // totals row 0 is always zero, delta row k + 1 is cleared by iteration k's kernel and
+    // row 0 by the solve kernel that ended the previous run
     for (int k = 0; k < iters; ++k) {
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 0], ctx->stream));
         launch_iteration(ctx, k, ctx->partials.as<double>());
@@ -324,7 +329,8 @@ int enqueue_loop(svicp_ctx *ctx, int iters, bool timed)
     // start of the following iteration's kernel
     hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->totals.as<double>(),
                        ctx->deltas.as<double>(), ctx->state.as<IcpState>(),
-                       ctx->xhist.as<double>(), ctx->ihist.as<double>(), iters - 1);
+                       ctx->xhist.as<double>(), ctx->ihist.as<double>(), iters - 1,
+                       ctx->h_state_dev);
     LAUNCHCHK("solve_kernel");
     return SVICP_OK;
 }
@@ -751,9 +757,7 @@ int svicp_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info
         rc = enqueue_loop(ctx, iterations, timed);
         if (rc) return rc;
     }
-    HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->state.p, sizeof(IcpState), hipMemcpyDeviceToHost,
-                          ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // the last kernel wrote h_state
     ctx->cur = iterations > 1 ? 1 : 0;
     ctx->last_iters = iterations;
     ctx->last_was_p2p = false;
@@ -896,7 +900,8 @@ int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info)
     if (ctx->shard_iter < 1) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_finish: no iteration was run");
     hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->totals.as<double>(),
                        ctx->deltas.as<double>(), ctx->state.as<IcpState>(),
-                       ctx->xhist.as<double>(), ctx->ihist.as<double>(), ctx->shard_iter - 1);
+                       ctx->xhist.as<double>(), ctx->ihist.as<double>(), ctx->shard_iter - 1,
+                       (IcpState *)nullptr);
     LAUNCHCHK("solve_kernel");
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->state.p, sizeof(IcpState), hipMemcpyDeviceToHost,
                           ctx->stream));

@@ -507,16 +507,22 @@ __device__ inline void solve_and_update(const double *base, const double *delta,
         const double r0 = r == 0 ? R[0] : r == 1 ? R[3] : R[6];
         const double r1 = r == 0 ? R[1] : r == 1 ? R[4] : R[7];
         const double r2 = r == 0 ? R[2] : r == 1 ? R[5] : R[8];
-        tnew = r0 * st->Trans[c] + r1 * st->Trans[4 + c] + r2 * st->Trans[8 + c];
+        // the first iteration of a run starts from the identity (CPoint2PlaneICP.cpp:33)
+        const double p0 = iter == 0 ? (c == 0 ? 1.0 : 0.0) : st->Trans[c];
+        const double p1 = iter == 0 ? (c == 1 ? 1.0 : 0.0) : st->Trans[4 + c];
+        const double p2 = iter == 0 ? (c == 2 ? 1.0 : 0.0) : st->Trans[8 + c];
+        tnew = r0 * p0 + r1 * p1 + r2 * p2;
         if (c == 3) tnew += (r == 0 ? x[3] : r == 1 ? x[4] : x[5]);
     }
+    if (iter == 0 && t >= 12 && t < 16) tnew = t == 15 ? 1.0 : 0.0;   // last row of the 4x4
     wave_lds_sync();
-    if (t < 12) st->Trans[t] = tnew;
+    if (t < 12 || (iter == 0 && t < 16)) st->Trans[t] = tnew;
     if (t < kNumSums) st->S[t] = stat;
     const double s27 = lane_bcast(stat, 27), s28 = lane_bcast(stat, 28), s29 = lane_bcast(stat, 29);
     if (t != 0) return;
 
-    if (!ok) st->status = 4;   // SVICP_ERR_SINGULAR
+    if (iter == 0) st->status = ok ? 0 : 4;   // SVICP_ERR_SINGULAR
+    else if (!ok) st->status = 4;
 #pragma unroll
     for (int k = 0; k < 9; ++k) st->R[k] = R[k];
     st->T[0] = x[3]; st->T[1] = x[4]; st->T[2] = x[5];
@@ -602,6 +608,10 @@ __device__ __forceinline__ void iterate_tile(
     }
     double old_row = 0.0;
     if (APPLY && threadIdx.x < 30) old_row = partials[(size_t)threadIdx.x * nb + tile];
+    // the next iteration's delta row starts at zero (the buffer holds one row more
+    // than the longest run; row 0 is cleared by the kernel that ends a run)
+    if (tile == 0 && threadIdx.x >= 32 && threadIdx.x < 32 + kNumSums)
+        deltas[(size_t)(iter + 1) * kNumSums + (threadIdx.x - 32)] = 0.0;
 
     // ---- B: solve the previous iteration's system ----
     double R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1, T0 = 0, T1 = 0,
@@ -837,6 +847,8 @@ __global__ __launch_bounds__(64) void batch_solve_kernel(const BatchPair *__rest
     solve_and_update(P->totals + (size_t)iter * kNumSums, P->deltas + (size_t)iter * kNumSums,
                      P->totals + (size_t)(iter + 1) * kNumSums, P->st, P->X_hist, P->info_hist, iter,
                      true, rt);
+    __syncthreads();
+    if (threadIdx.x < kNumSums) P->deltas[threadIdx.x] = 0.0;   // clean for the pair's next run
 }
 
 // Gathers every pair's state into one array for a single copy to the host.
@@ -852,14 +864,25 @@ __global__ void batch_collect_kernel(const BatchPair *__restrict__ pairs, int co
 
 // One wave: solve the system of iteration `iter` and record the result (the
 // last iteration of a run has no following iteration kernel to do it).
-__global__ __launch_bounds__(64) void solve_kernel(double *totals, const double *deltas,
+__global__ __launch_bounds__(64) void solve_kernel(double *totals, double *deltas,
                                                    IcpState *st, double *X_hist,
-                                                   double *info_hist, int iter)
+                                                   double *info_hist, int iter, IcpState *host_copy)
 {
     __shared__ double rt[12];
     solve_and_update(totals + (size_t)iter * kNumSums, deltas + (size_t)iter * kNumSums,
                      totals + (size_t)(iter + 1) * kNumSums, st, X_hist, info_hist, iter, true,
                      rt);
+    __syncthreads();
+    // leave the first delta row clean for the next run, and hand the state to the
+    // host through mapped memory (one store per lane instead of a copy command)
+    if (threadIdx.x < kNumSums) deltas[threadIdx.x] = 0.0;
+    if (host_copy) {
+        constexpr int W = sizeof(IcpState) / sizeof(double);
+        __threadfence();
+        for (int k = threadIdx.x; k < W; k += 64)
+            reinterpret_cast<double *>(host_copy)[k] = reinterpret_cast<volatile double *>(st)[k];
+        __threadfence_system();
+    }
 }
 
 __global__ void reset_state_kernel(IcpState *st)
