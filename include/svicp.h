@@ -227,6 +227,11 @@ int svicp_batch_last_ms(const svicp_batch *batch, double *ms);
  * kernel), and the number of launches averaged. */
 int svicp_kernel_times(svicp_ctx *ctx, double *fused_ms, double *solve_ms, int *launches);
 
+/* Number of source points that went through the neighbour search in each
+ * iteration of the last svicp_run (`iterations` entries); the others kept
+ * their correspondence by the proof described at options.coherent. */
+int svicp_search_counts(svicp_ctx *ctx, double *counts_out);
+
 /* The same two quantities per iteration over the last timed svicp_run:
  * `iterations` entries each.  Either pointer may be NULL. */
 int svicp_iteration_times(svicp_ctx *ctx, double *fused_ms_out, double *solve_ms_out);

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvicp.so")
+LIB_PATH = os.environ.get("SVICP_LIBRARY") or os.path.join(_HERE, "libsvicp.so")   # the override serves A/B builds
 
 OK, ERR_ARG, ERR_HIP, ERR_GRID, ERR_SINGULAR, ERR_NO_DEVICE = range(6)
 
@@ -70,6 +70,7 @@ SYMBOLS = {
     "svicp_iteration_times": (C.c_int, [_ctx, _dp, _dp]),
     "svicp_time_nn": (C.c_int, [_ctx, C.c_int, C.c_int, _dp]),
     "svicp_sizes": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "svicp_search_counts": (C.c_int, [_ctx, _dp]),
     "svicp_run_point2point": (C.c_int, [_ctx, C.c_int, _dp, C.POINTER(Info)]),
     "svicp_get_history_rt": (C.c_int, [_ctx, _dp, _dp]),
     "svicp_batch_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.POINTER(C.c_void_p)]),

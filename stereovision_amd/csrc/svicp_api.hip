@@ -262,11 +262,11 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
         HIPCHK(ctx->xhist.reserve(sizeof(double) * 6 * cap));
         HIPCHK(ctx->ihist.reserve(sizeof(double) * 4 * cap));
         HIPCHK(ctx->totals.reserve(sizeof(double) * kNumSums * (cap + 1)));
-        HIPCHK(ctx->deltas.reserve(sizeof(double) * kNumSums * (cap + 1)));
+        HIPCHK(ctx->deltas.reserve(sizeof(double) * kDeltaRow * (cap + 1)));
         // totals row 0 (the sums "before iteration 0") stays zero for good; delta rows are
         // cleared by the kernels themselves from here on
         HIPCHK(hipMemsetAsync(ctx->totals.p, 0, sizeof(double) * kNumSums * (cap + 1), ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->deltas.p, 0, sizeof(double) * kNumSums * (cap + 1), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->deltas.p, 0, sizeof(double) * kDeltaRow * (cap + 1), ctx->stream));
         ctx->hist_cap = cap;
     }
     if (!ctx->h_state) {
@@ -801,6 +801,26 @@ int svicp_get_history(svicp_ctx *ctx, double *X_out, double *info_out)
     return SVICP_OK;
 }
 
+int svicp_search_counts(svicp_ctx *ctx, double *counts_out)
+{
+    if (!ctx || !counts_out) return fail(ctx, SVICP_ERR_ARG, "svicp_search_counts: NULL argument");
+    if (ctx->last_iters <= 0 || ctx->last_was_p2p)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_search_counts: no point-to-plane run yet");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<double> rows((size_t)kDeltaRow * ctx->last_iters);
+    HIPCHK(hipMemcpyAsync(rows.data(), ctx->deltas.p, sizeof(double) * rows.size(),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // row 0 was cleared for the next run; iteration 0 searches every point
+    counts_out[0] = (double)ctx->n;
+    for (int k = 1; k < ctx->last_iters; ++k) {
+        double c = 0.0;
+        for (int cp = 0; cp < kDeltaCopies; ++cp) c += rows[(size_t)k * kDeltaRow + cp * kNumSums + 31];
+        counts_out[k] = c;
+    }
+    return SVICP_OK;
+}
+
 int svicp_correspondences(svicp_ctx *ctx, int32_t *idx_out, float *d2_out)
 {
     if (!ctx || !idx_out || !d2_out)
@@ -858,7 +878,7 @@ int svicp_shard_begin(svicp_ctx *ctx)
                        ctx->state.as<IcpState>());
     LAUNCHCHK("reset_state_kernel");
     HIPCHK(hipMemsetAsync(ctx->totals.p, 0, sizeof(double) * kNumSums, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->deltas.p, 0, sizeof(double) * kNumSums * ctx->hist_cap, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->deltas.p, 0, sizeof(double) * kDeltaRow * ctx->hist_cap, ctx->stream));
     ctx->shard_iter = 0;
     ctx->cur = 0;
     return SVICP_OK;
@@ -874,8 +894,9 @@ int svicp_shard_accumulate(svicp_ctx *ctx, double *dev_partial32)
     launch_iteration(ctx, k, ctx->partials.as<double>());
     LAUNCHCHK("icp_iterate_kernel");
     // this rank's change of the sums in iteration k
-    HIPCHK(hipMemcpyAsync(dev_partial32, ctx->deltas.as<double>() + (size_t)k * kNumSums,
-                          sizeof(double) * kNumSums, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(fold_delta_kernel, dim3(1), dim3(64), 0, ctx->stream,
+                       ctx->deltas.as<double>() + (size_t)k * kDeltaRow, dev_partial32);
+    LAUNCHCHK("fold_delta_kernel");
     if (ctx->shard_iter >= 1) ctx->cur = 1;
     return SVICP_OK;
 }
@@ -886,8 +907,9 @@ int svicp_shard_update(svicp_ctx *ctx, const double *dev_sum32)
     HIPCHK(hipSetDevice(ctx->device));
     // the summed change replaces this rank's own; the next svicp_shard_accumulate
     // (or _finish) adds it to the running totals and solves
-    HIPCHK(hipMemcpyAsync(ctx->deltas.as<double>() + (size_t)ctx->shard_iter * kNumSums, dev_sum32,
-                          sizeof(double) * kNumSums, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(unfold_delta_kernel, dim3(1), dim3(256), 0, ctx->stream, dev_sum32,
+                       ctx->deltas.as<double>() + (size_t)ctx->shard_iter * kDeltaRow);
+    LAUNCHCHK("unfold_delta_kernel");
     ctx->shard_iter++;
     ctx->last_iters = ctx->shard_iter;
     return SVICP_OK;
@@ -970,7 +992,7 @@ int svicp_run_point2point(svicp_ctx *ctx, int iterations, double T_out[16], svic
     if (rc) return rc;
     {
         void *a = ctx->p2p_sums.p, *b = ctx->rthist.p;
-        HIPCHK(ctx->p2p_sums.reserve(sizeof(double) * kNumSums * ctx->hist_cap));
+        HIPCHK(ctx->p2p_sums.reserve(sizeof(double) * kDeltaRow * ctx->hist_cap));
         HIPCHK(ctx->rthist.reserve(sizeof(double) * 12 * ctx->hist_cap));
         if (a != ctx->p2p_sums.p || b != ctx->rthist.p) drop_graph(ctx);
     }
@@ -985,9 +1007,9 @@ int svicp_run_point2point(svicp_ctx *ctx, int iterations, double T_out[16], svic
         const float thr = ctx->opt.dist_threshold;
         hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(64), 0, ctx->stream, state);
         LAUNCHCHK("reset_state_kernel");
-        HIPCHK(hipMemsetAsync(sums, 0, sizeof(double) * kNumSums * iterations, ctx->stream));
+        HIPCHK(hipMemsetAsync(sums, 0, sizeof(double) * kDeltaRow * iterations, ctx->stream));
         for (int k = 0; k < iterations; ++k) {
-            double *sk = sums + (size_t)k * kNumSums;
+            double *sk = sums + (size_t)k * kDeltaRow;
             const float *cx = k <= 1 ? x0 : wx, *cy = k <= 1 ? y0 : wy, *cz = k <= 1 ? z0 : wz;
             if (k == 0)
                 hipLaunchKernelGGL((p2p_match_kernel<false>), dim3(nb), dim3(256), 0, ctx->stream,

@@ -20,6 +20,11 @@ namespace svicp {
 
 constexpr int kBlockThreads = 256;
 constexpr int kNumSums = 32;   // 21 JtJ + 6 Jtr + inliers + sum w b^2 + sum w + 2 pad
+// Same-address fp64 atomics serialise in L2 (about 6 ns each): the per-iteration change of
+// the sums is therefore kept in kDeltaCopies copies, a tile adds to copy (tile mod copies),
+// and the solve adds the copies up in a fixed order.
+constexpr int kDeltaCopies = 4;   // measured: 1 copy costs 9 us per search-heavy iteration, 16 slow the solve
+constexpr int kDeltaRow = kDeltaCopies * kNumSums;   // doubles per iteration
 constexpr int kMaxRing = 3;    // exact search: rings tried before the brute-force pass
 
 struct GridDesc {
@@ -404,7 +409,7 @@ __device__ __forceinline__ double lane_bcast(double v, int lane)
 }
 
 // Wave-parallel solve, called by ONE full wave (64 lanes).  The 32 sums are
-// base[] + delta[] (global memory).  Results: R (9) and T (3) to out_rt (LDS);
+// base[] + the kDeltaCopies copies of delta[] (global memory).  Results: R (9) and T (3) to out_rt (LDS);
 // when `record`, also the sums to totals[], the state, the accumulated
 // transform and the history rows.
 //
@@ -426,16 +431,21 @@ __device__ inline void solve_and_update(const double *base, const double *delta,
     // running totals of the normal equations: the totals after the iteration
     // before, plus what the tiles that changed since have added or taken away.
     // Upper triangle: element (r, c), r <= c, sits at r*6 - r(r-1)/2 + (c - r).
+    double stat = 0.0;                      // lanes 0..29 carry sum t
+    if (t < 30) {
+        double dsum = 0.0;
+#pragma unroll
+        for (int cp = 0; cp < kDeltaCopies; ++cp) dsum += delta[cp * kNumSums + t];
+        stat = base[t] + dsum;
+    }
+    if (record && t < kNumSums) totals[t] = stat;
     double m[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         const int lo = row < c ? row : c, hi = row < c ? c : row;
         const int at = row < 6 ? lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo) : 21 + c;
-        m[c] = base[at] + delta[at];
+        m[c] = __shfl(stat, at, 64);
     }
-    double stat = 0.0;                      // lanes 0..31 also carry sum t for the record
-    if (t < kNumSums) stat = t < 30 ? base[t] + delta[t] : 0.0;
-    if (record && t < kNumSums) totals[t] = stat;
 
     // scaling d = diag^-1/2
     double d[6];
@@ -610,8 +620,9 @@ __device__ __forceinline__ void iterate_tile(
     if (APPLY && threadIdx.x < 30) old_row = partials[(size_t)threadIdx.x * nb + tile];
     // the next iteration's delta row starts at zero (the buffer holds one row more
     // than the longest run; row 0 is cleared by the kernel that ends a run)
-    if (tile == 0 && threadIdx.x >= 32 && threadIdx.x < 32 + kNumSums)
-        deltas[(size_t)(iter + 1) * kNumSums + (threadIdx.x - 32)] = 0.0;
+    if (tile == 0)
+        for (int k = threadIdx.x; k < kDeltaRow; k += kItThreads)
+            deltas[(size_t)(iter + 1) * kDeltaRow + k] = 0.0;
 
     // ---- B: solve the previous iteration's system ----
     double R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1, T0 = 0, T1 = 0,
@@ -620,7 +631,7 @@ __device__ __forceinline__ void iterate_tile(
         // totals[k]: sums after iteration k - 1 (row 0 is zero); deltas[k]: changes made by iteration k
         if (wv == 0)
             solve_and_update(totals + (size_t)(iter - 1) * kNumSums,
-                             deltas + (size_t)(iter - 1) * kNumSums,
+                             deltas + (size_t)(iter - 1) * kDeltaRow,
                              totals + (size_t)iter * kNumSums, st, X_hist, info_hist, iter - 1,
                              tile == 0, shRT);
         __syncthreads();
@@ -739,6 +750,12 @@ __device__ __forceinline__ void iterate_tile(
     }
     __syncthreads();
 
+    // slot 31 of the iteration's delta row counts the searched points (a statistic
+    // for the caller; the solve reads slots 0..29 only)
+    if (threadIdx.x == 0 && total > 0)
+        atomicAdd(deltas + (size_t)iter * kDeltaRow + (tile & (kDeltaCopies - 1)) * kNumSums + 31,
+                  (double)total);
+
     // ---- G: search the queued points (CPoint2PlaneICP.cpp:65-67) ----
     for (int q = threadIdx.x; q < total; q += kItThreads) {
         const float4 e = queue[q];
@@ -769,7 +786,9 @@ __device__ __forceinline__ void iterate_tile(
     if (threadIdx.x < 30) {
         partials[(size_t)threadIdx.x * nb + tile] = s;
         const double d = s - old_row;
-        if (d != 0.0) atomicAdd(deltas + (size_t)iter * kNumSums + threadIdx.x, d);
+        if (d != 0.0)
+            atomicAdd(deltas + (size_t)iter * kDeltaRow + (tile & (kDeltaCopies - 1)) * kNumSums +
+                          threadIdx.x, d);
     }
 }
 
@@ -836,7 +855,7 @@ __global__ __launch_bounds__(64) void batch_reset_kernel(const BatchPair *__rest
     if (t < 16) st->Trans[t] = (t % 5 == 0) ? 1.0 : 0.0;
     if (t < kNumSums) { st->S[t] = 0.0; P->totals[t] = 0.0; }
     if (t == 0) st->status = 0;
-    for (int k = t; k < iters * kNumSums; k += 64) P->deltas[k] = 0.0;
+    for (int k = t; k < iters * kDeltaRow; k += 64) P->deltas[k] = 0.0;
 }
 
 // One wave per pair: the last iteration's solve.
@@ -844,11 +863,11 @@ __global__ __launch_bounds__(64) void batch_solve_kernel(const BatchPair *__rest
 {
     __shared__ double rt[12];
     const BatchPair *P = pairs + blockIdx.x;
-    solve_and_update(P->totals + (size_t)iter * kNumSums, P->deltas + (size_t)iter * kNumSums,
+    solve_and_update(P->totals + (size_t)iter * kNumSums, P->deltas + (size_t)iter * kDeltaRow,
                      P->totals + (size_t)(iter + 1) * kNumSums, P->st, P->X_hist, P->info_hist, iter,
                      true, rt);
     __syncthreads();
-    if (threadIdx.x < kNumSums) P->deltas[threadIdx.x] = 0.0;   // clean for the pair's next run
+    for (int k = threadIdx.x; k < kDeltaRow; k += 64) P->deltas[k] = 0.0;   // clean for the pair's next run
 }
 
 // Gathers every pair's state into one array for a single copy to the host.
@@ -869,13 +888,13 @@ __global__ __launch_bounds__(64) void solve_kernel(double *totals, double *delta
                                                    double *info_hist, int iter, IcpState *host_copy)
 {
     __shared__ double rt[12];
-    solve_and_update(totals + (size_t)iter * kNumSums, deltas + (size_t)iter * kNumSums,
+    solve_and_update(totals + (size_t)iter * kNumSums, deltas + (size_t)iter * kDeltaRow,
                      totals + (size_t)(iter + 1) * kNumSums, st, X_hist, info_hist, iter, true,
                      rt);
     __syncthreads();
     // leave the first delta row clean for the next run, and hand the state to the
     // host through mapped memory (one store per lane instead of a copy command)
-    if (threadIdx.x < kNumSums) deltas[threadIdx.x] = 0.0;
+    for (int k = threadIdx.x; k < kDeltaRow; k += 64) deltas[k] = 0.0;
     if (host_copy) {
         constexpr int W = sizeof(IcpState) / sizeof(double);
         __threadfence();
@@ -883,6 +902,24 @@ __global__ __launch_bounds__(64) void solve_kernel(double *totals, double *delta
             reinterpret_cast<double *>(host_copy)[k] = reinterpret_cast<volatile double *>(st)[k];
         __threadfence_system();
     }
+}
+
+// Sharded runs: this rank's change of the sums in one iteration, copies added up.
+__global__ void fold_delta_kernel(const double *__restrict__ delta_row, double *__restrict__ out32)
+{
+    const int t = threadIdx.x;
+    if (t >= kNumSums) return;
+    double s = 0.0;
+    for (int cp = 0; cp < kDeltaCopies; ++cp) s += delta_row[cp * kNumSums + t];
+    out32[t] = s;
+}
+
+// Sharded runs: the change summed over all ranks replaces the rank's own (copy 0 holds
+// it, the other copies are cleared).
+__global__ void unfold_delta_kernel(const double *__restrict__ in32, double *__restrict__ delta_row)
+{
+    for (int k = threadIdx.x; k < kDeltaRow; k += blockDim.x)
+        delta_row[k] = k < kNumSums ? in32[k] : 0.0;
 }
 
 __global__ void reset_state_kernel(IcpState *st)

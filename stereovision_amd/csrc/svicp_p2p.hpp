@@ -18,7 +18,8 @@ constexpr int kP2PTile = 1024;      // points per block, 4 per thread
 constexpr int kP2PSums = 18;        // move xyz, ref xyz, weight, count, sum w d2, W (9)
 
 // Block sum of NV per-thread doubles; the totals are added to out[0..NV) with one
-// fp64 atomic per value by the first NV threads.
+// fp64 atomic per value by the first NV threads.  Callers spread the blocks over
+// kDeltaCopies copies of `out`: same-address atomics serialise in L2.
 template <int NV>
 __device__ __forceinline__ void block_atomic_add(double (&v)[NV], double *out, double (*red)[32])
 {
@@ -89,7 +90,16 @@ __global__ __launch_bounds__(256, 4) void p2p_match_kernel(
         }
         tp[i] = rec;
     }
-    block_atomic_add<9>(acc, sums, red);
+    block_atomic_add<9>(acc, sums + ((int)blockIdx.x & (kDeltaCopies - 1)) * kNumSums, red);
+}
+
+// Sum t of an iteration: the kDeltaCopies copies added in a fixed order.
+__device__ __forceinline__ double p2p_sum(const double *__restrict__ sums, int t)
+{
+    double s = 0.0;
+#pragma unroll
+    for (int cp = 0; cp < kDeltaCopies; ++cp) s += sums[cp * kNumSums + t];
+    return s;
 }
 
 __global__ __launch_bounds__(256, 4) void p2p_cov_kernel(
@@ -99,11 +109,13 @@ __global__ __launch_bounds__(256, 4) void p2p_cov_kernel(
     __shared__ double red[4][32];
     const int nb = (int)gridDim.x;
     const long long tile0 = (long long)xcd_contiguous((int)blockIdx.x, nb) * kP2PTile;
-    const double sw = sums[6];
+    const double sw = p2p_sum(sums, 6);
     // centroids rounded to fp32 once (:125-126); count as the reference's float divisor (:144)
-    const float mmx = (float)(sums[0] / sw), mmy = (float)(sums[1] / sw), mmz = (float)(sums[2] / sw);
-    const float mrx = (float)(sums[3] / sw), mry = (float)(sums[4] / sw), mrz = (float)(sums[5] / sw);
-    const float fcount = (float)sums[7];
+    const float mmx = (float)(p2p_sum(sums, 0) / sw), mmy = (float)(p2p_sum(sums, 1) / sw),
+                mmz = (float)(p2p_sum(sums, 2) / sw);
+    const float mrx = (float)(p2p_sum(sums, 3) / sw), mry = (float)(p2p_sum(sums, 4) / sw),
+                mrz = (float)(p2p_sum(sums, 5) / sw);
+    const float fcount = (float)p2p_sum(sums, 7);
     double acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.0;
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(256, 4) void p2p_cov_kernel(
                 acc[3 * j + c] += (double)term;
             }
     }
-    block_atomic_add<9>(acc, sums + 9, red);
+    block_atomic_add<9>(acc, sums + ((int)blockIdx.x & (kDeltaCopies - 1)) * kNumSums + 9, red);
 }
 
 // One-sided Jacobi SVD of a 3x3 matrix, columns ordered by descending singular
@@ -191,10 +203,12 @@ __device__ inline void kabsch_rotation(const double W[9], double R[9])
 }
 
 // rt_hist: 12 doubles per iteration {R row-major, T}; info_hist: {count, sum w, sum w d2, step}.
-__global__ void p2p_solve_kernel(const double *__restrict__ sums, IcpState *st, double *rt_hist,
+__global__ void p2p_solve_kernel(const double *__restrict__ sum_copies, IcpState *st, double *rt_hist,
                                  double *info_hist, int iter)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double sums[kP2PSums];
+    for (int t = 0; t < kP2PSums; ++t) sums[t] = p2p_sum(sum_copies, t);
     double R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, T[3] = { 0, 0, 0 };
     const double count = sums[7], sw = sums[6];
     if (count > 0.0 && sw > 0.0) {

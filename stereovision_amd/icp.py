@@ -147,6 +147,12 @@ class Context:
         self._check(self._lib.svicp_get_history(self._h, _dp(X), _dp(I)))
         return X, I
 
+    def search_counts(self):
+        """Points searched per iteration of the last run()."""
+        out = np.zeros(getattr(self, "_iters", 0), np.float64)
+        self._check(self._lib.svicp_search_counts(self._h, _dp(out)))
+        return out
+
     def correspondences(self):
         _, n = self.sizes()
         idx = np.empty(n, np.int32)
