@@ -413,7 +413,7 @@ int svicp_destroy(svicp_ctx *ctx)
                        &ctx->vals_b, &ctx->marks, &ctx->ranks, &ctx->block_of_rank,
                        &ctx->sort_tmp, &ctx->bbox6, &ctx->knn_idx, &ctx->knn_d2,
                        &ctx->unresolved, &ctx->n_unres, &ctx->partials, &ctx->totals, &ctx->deltas, &ctx->state, &ctx->xhist,
-                       &ctx->ihist };
+                       &ctx->ihist, &ctx->p2p_sums, &ctx->rthist };
     for (DevBuf *b : bufs) b->release();
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
