@@ -424,3 +424,40 @@ def test_batch_many_small_pairs_throughput_property():
     T0, _ = ctxs[5].run(30)
     assert np.abs(T0 - Ts[5]).max() < 1e-10
     print(f"batch of 64 x 16384 points, 30 iterations: {batch.last_ms():.3f} ms")
+
+
+@pytest.mark.parametrize("side,iters", [(1024, 4), (4096, 2)])
+def test_full_size_iterations_against_oracle(ctx, po, side, iters):
+    """The benchmark's 1M-point pair and the 16.8M-point pair of the sharded configuration,
+    first iterations, against the oracle on all host threads: inlier counts equal, solve
+    results within 1e-9 (rotation) / 1e-9 x extent (translation)."""
+    from stereovision_amd import synth
+    tgt, nrm, src, _ = synth.make_pair(side)
+    ctx.set_target(tgt, nrm)
+    ctx.set_source(src)
+    T, info = ctx.run(iters)
+    X, I = ctx.history()
+    searched = ctx.search_counts()
+    r = po.icp_point2plane(po.KDTree(tgt), nrm, src, iters, threads=po.max_threads(), history=False)
+    extent = float(np.ptp(tgt, axis=0).max())
+    assert np.array_equal(I[:, 0], r["info"][:, 0])                 # inliers per iteration
+    assert np.abs(X[:, :3] - r["X"][:, :3]).max() < 1e-9
+    assert np.abs(X[:, 3:] - r["X"][:, 3:]).max() < 1e-9 * extent
+    assert np.abs(T - r["trans"]).max() < 1e-9 * extent
+    assert searched[0] == len(src) and np.all(searched[1:] <= len(src))
+    assert np.abs(ctx.get_source() - r["src"]).max() <= 2e-4        # a few ulp at |x| ~ 1e4
+
+
+def test_search_counts_fall_as_the_registration_settles(ctx):
+    from stereovision_amd import synth
+    tgt, nrm, src, _ = synth.make_pair(256)
+    ctx.set_target(tgt, nrm)
+    ctx.set_source(src)
+    ctx.run(12)
+    s = ctx.search_counts()
+    assert s[0] == len(src) and s[-1] < 0.01 * len(src)
+    ctx.set_options(coherent=0)
+    ctx.set_source(src)
+    ctx.run(4)
+    assert np.all(ctx.search_counts() == len(src))
+    ctx.set_options(coherent=1)
