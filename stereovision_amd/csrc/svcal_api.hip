@@ -157,9 +157,14 @@ int svcal_eval(svcal_ctx *ctx)
     if (!ctx) return SVICP_ERR_ARG;
     if (!ctx->have_params) return cfail(ctx, SVICP_ERR_ARG, "svcal_eval: set the parameters first");
     CHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(cal_eval_kernel, dim3(ctx->V), dim3(kThreads), 0, ctx->stream, ctx->params,
-                       ctx->k, ctx->V, ctx->C, ctx->stereo, ctx->world, ctx->left, ctx->right,
-                       ctx->gram_view, ctx->residual);
+    if (ctx->k == 5)
+        hipLaunchKernelGGL(cal_eval_kernel<5>, dim3(ctx->V), dim3(kThreads), 0, ctx->stream,
+                           ctx->params, ctx->V, ctx->C, ctx->stereo, ctx->world, ctx->left,
+                           ctx->right, ctx->gram_view, ctx->residual);
+    else
+        hipLaunchKernelGGL(cal_eval_kernel<2>, dim3(ctx->V), dim3(kThreads), 0, ctx->stream,
+                           ctx->params, ctx->V, ctx->C, ctx->stereo, ctx->world, ctx->left,
+                           ctx->right, ctx->gram_view, ctx->residual);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "cal_eval_kernel", e);
     hipLaunchKernelGGL(cal_reduce_kernel, dim3((ctx->stereo ? 2 : 1) * kGram), dim3(256), 0,

@@ -2,14 +2,13 @@
 // residuals and central-difference Jacobian rows, reduced per view to the Gram
 // matrix of [J | e], then over views.
 //
-// Layout: one block per view.  The first 26 threads build the 13 + 13 extrinsic
-// matrices the view needs (base and +/- eps for each of its six left-extrinsic
-// parameters; pose * left extrinsic for the base pose and +/- eps of each of the
-// six pose parameters) in LDS.  Each thread then takes corners; per corner and
-// camera it writes two 16-vectors u = [J row (nI + 6 columns, zero padded to
-// 15), e] to LDS, and the block sums the upper triangle of u u^T (136 numbers
-// per camera) over the view's corners.  Everything is fp64, as the reference
-// (Data_Type = double).
+// Layout: one block per view, one wave per camera.  The first 13 lanes of each wave build
+// the 13 extrinsic matrices its camera needs (base and +/- eps of each of the six
+// left-extrinsic parameters; pose * left extrinsic for the base pose and +/- eps of each
+// of the six pose parameters) in LDS.  Each lane then takes corners; per corner it forms
+// two 16-vectors u = [J row (nI + 6 columns, zero padded to 15), e], and the wave sums
+// u u^T over the view's corners on the fp64 matrix cores.  Everything is fp64, as the
+// reference (Data_Type = double).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -52,17 +51,25 @@ __device__ inline void ext_from(const double p[6], double *E)
     }
 }
 
-// CStereoCameraCalibration.cpp:25-50; intr = {fx, fy, cx, cy}, skew 0
-__device__ __forceinline__ void value(const double intr[4], const double dist[5], int k,
-                                      const double *E, double wx, double wy, double &u, double &v)
+// CStereoCameraCalibration.cpp:25-50; intr = {fx, fy, cx, cy}, skew 0.
+// The projection in two stages, so that perturbations of the intrinsic parameters reuse the
+// geometry: the same operations on the same inputs as value(), hence the same bits.
+__device__ __forceinline__ void project_geom(const double *E, double wx, double wy, double &nx,
+                                             double &ny, double &r)
 {
     double c0 = E[0] * wx + E[1] * wy + E[2] * 0.0 + E[3] * 1.0;
     double c1 = E[4] * wx + E[5] * wy + E[6] * 0.0 + E[7] * 1.0;
     double c2 = E[8] * wx + E[9] * wy + E[10] * 0.0 + E[11] * 1.0;
-    double nx = c0 / c2, ny = c1 / c2;
-    double r = nx * nx + ny * ny;
+    nx = c0 / c2; ny = c1 / c2;
+    r = nx * nx + ny * ny;
+}
+
+template <int K>
+__device__ __forceinline__ void project_pix(const double intr[4], const double dist[5], double nx,
+                                            double ny, double r, double &u, double &v)
+{
     double xe, ye;
-    if (k == 2) {
+    if (K == 2) {
         xe = nx * (1.0 + dist[0] * r + dist[1] * r * r);
         ye = ny * (1.0 + dist[0] * r + dist[1] * r * r);
     } else {
@@ -75,51 +82,77 @@ __device__ __forceinline__ void value(const double intr[4], const double dist[5]
     v = intr[1] * ye + intr[3];
 }
 
-// One camera's two rows of [J | e] for one corner: columns 0..nI-1 intrinsics
-// and distortion, nI..nI+5 the six pose-like parameters whose +/- eps matrices
-// are Evar[1 + 2q], Evar[2 + 2q]; the residual (projected - observed) in slot 15.
-__device__ inline void rows_for(const double *ip /* nI values */, int k, const double *Evar,
-                                double wx, double wy, double ox, double oy, double *u0, double *u1)
+// One camera's two rows of [J | e] for one corner: columns 0..nI-1 intrinsics and
+// distortion, nI..nI+5 the six pose-like parameters whose +/- eps matrices are
+// Evar[1 + 2q], Evar[2 + 2q]; the residual (projected - observed) in slot 15.
+// Central differences with eps = 1e-6 exactly as the reference forms them
+// (CStereoCameraCalibration.cpp:101-108, :122-123).
+template <int K>
+__device__ __forceinline__ void rows_for(const double *ip /* nI values */, const double *Evar,
+                                         double wx, double wy, double ox, double oy,
+                                         double (&u0)[16], double (&u1)[16])
 {
-    const int nI = 4 + k;
-    double intr[4] = { ip[0], ip[1], ip[2], ip[3] };
-    double dist[5] = { ip[4], ip[5], k == 5 ? ip[6] : 0.0, k == 5 ? ip[7] : 0.0,
-                       k == 5 ? ip[8] : 0.0 };
-    double a, b, c, d;
-    value(intr, dist, k, Evar, wx, wy, a, b);
+    constexpr int nI = 4 + K;
+    const double intr[4] = { ip[0], ip[1], ip[2], ip[3] };
+    const double dist[5] = { ip[4], ip[5], K == 5 ? ip[6] : 0.0, K == 5 ? ip[7] : 0.0,
+                             K == 5 ? ip[8] : 0.0 };
+#pragma unroll
     for (int q = 0; q < 16; ++q) { u0[q] = 0.0; u1[q] = 0.0; }
+    double nx, ny, r, a, b, c, d;
+    project_geom(Evar, wx, wy, nx, ny, r);
+    project_pix<K>(intr, dist, nx, ny, r, a, b);
     u0[15] = a - ox; u1[15] = b - oy;
-    for (int col = 0; col < nI; ++col) {
+#pragma unroll
+    for (int col = 0; col < 4; ++col) {
         double iu[4] = { intr[0], intr[1], intr[2], intr[3] }, il[4] = { intr[0], intr[1], intr[2], intr[3] };
-        double du[5] = { dist[0], dist[1], dist[2], dist[3], dist[4] }, dl[5] = { dist[0], dist[1], dist[2], dist[3], dist[4] };
-        if (col < 4) { iu[col] += kEps; il[col] -= kEps; }
-        else { du[col - 4] += kEps; dl[col - 4] -= kEps; }
-        value(iu, du, k, Evar, wx, wy, a, b);
-        value(il, dl, k, Evar, wx, wy, c, d);
+        iu[col] += kEps; il[col] -= kEps;
+        project_pix<K>(iu, dist, nx, ny, r, a, b);
+        project_pix<K>(il, dist, nx, ny, r, c, d);
         u0[col] = (a - c) / (2.0 * kEps);
         u1[col] = (b - d) / (2.0 * kEps);
     }
+#pragma unroll
+    for (int col = 0; col < K; ++col) {
+        double du[5] = { dist[0], dist[1], dist[2], dist[3], dist[4] }, dl[5] = { dist[0], dist[1], dist[2], dist[3], dist[4] };
+        du[col] += kEps; dl[col] -= kEps;
+        project_pix<K>(intr, du, nx, ny, r, a, b);
+        project_pix<K>(intr, dl, nx, ny, r, c, d);
+        u0[4 + col] = (a - c) / (2.0 * kEps);
+        u1[4 + col] = (b - d) / (2.0 * kEps);
+    }
+#pragma unroll
     for (int q = 0; q < 6; ++q) {
-        value(intr, dist, k, Evar + 12 * (1 + 2 * q), wx, wy, a, b);
-        value(intr, dist, k, Evar + 12 * (2 + 2 * q), wx, wy, c, d);
+        project_geom(Evar + 12 * (1 + 2 * q), wx, wy, nx, ny, r);
+        project_pix<K>(intr, dist, nx, ny, r, a, b);
+        project_geom(Evar + 12 * (2 + 2 * q), wx, wy, nx, ny, r);
+        project_pix<K>(intr, dist, nx, ny, r, c, d);
         u0[nI + q] = (a - c) / (2.0 * kEps);
         u1[nI + q] = (b - d) / (2.0 * kEps);
     }
 }
 
-// params: the parameter vector; gram_view: V x 2 x 136 (left, right) per view;
-// residual: 4 V C (stereo order) or 2 V C (monocular, sign flipped), may be null.
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kStageStride = 17;    // doubles per staged 16-vector (one of padding: no bank conflicts)
+
+// One block per view, one wave per camera.  A lane takes a corner, builds its two
+// 16-vectors u = [J row, 0.., e] in registers, and the wave adds u u^T to its 16 x 16
+// Gram matrix with the fp64 matrix instruction (16 x 16 x 4 per step: four corners'
+// vectors at a time, staged through LDS because the instruction wants component i of
+// corner k in lane 16 k + i).  params: the parameter vector; gram_view: V x 2 x 136
+// (upper triangles, left and right camera) per view; residual: 4 V C (stereo order) or
+// 2 V C (monocular, sign flipped), may be null.
+template <int K>
 __global__ __launch_bounds__(kThreads) void cal_eval_kernel(
-    const double *__restrict__ params, int k, int V, int C, int stereo,
+    const double *__restrict__ params, int V, int C, int stereo,
     const double *__restrict__ world_xy, const double *__restrict__ left_xy,
     const double *__restrict__ right_xy, double *__restrict__ gram_view,
     double *__restrict__ residual)
 {
-    __shared__ double ext[2][13 * 12];          // [camera][variant][3x4]
-    __shared__ double rows[kThreads][2][2][16]; // [corner in chunk][camera][row][16]
+    constexpr int nI = 4 + K;
+    __shared__ double ext[2][13 * 12];                       // [camera][variant][3x4]
+    __shared__ double stage[2][64 * kStageStride];           // [wave][corner][16 + 1]
     const int view = blockIdx.x;
-    const int nI = 4 + k;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, cam = t >> 6;
     const double *pE = params + (stereo ? 2 * nI : nI) + 6 * view;
     const double *pS = params + 2 * nI + 6 * V;
 
@@ -131,10 +164,10 @@ __global__ __launch_bounds__(kThreads) void cal_eval_kernel(
         ext_from(p, &ext[0][12 * t]);
     }
     __syncthreads();
-    if (stereo && t < 13) {
+    if (stereo && cam == 1 && lane < 13) {
         double p[6], S[12];
         for (int q = 0; q < 6; ++q) p[q] = pS[q];
-        if (t > 0) p[(t - 1) >> 1] += ((t - 1) & 1) ? -kEps : kEps;
+        if (lane > 0) p[(lane - 1) >> 1] += ((lane - 1) & 1) ? -kEps : kEps;
         ext_from(p, S);
         // pose * [left extrinsic; 0 0 0 1]  (CStereoCameraCalibration.cpp:573-579)
         const double *L = &ext[0][0];
@@ -143,61 +176,59 @@ __global__ __launch_bounds__(kThreads) void cal_eval_kernel(
                 double s = 0;
                 for (int kk = 0; kk < 3; ++kk) s += S[4 * r + kk] * L[4 * kk + c];
                 s += S[4 * r + 3] * (c == 3 ? 1.0 : 0.0);
-                ext[1][12 * t + 4 * r + c] = s;
+                ext[1][12 * lane + 4 * r + c] = s;
             }
     }
     __syncthreads();
+    if (cam == 1 && !stereo) return;                         // (whole wave)
 
-    // tasks: entry (a, b), a <= b, of the 16 x 16 Gram matrix of each camera
-    double sum[3] = { 0.0, 0.0, 0.0 };
-    int ta[3], tb[3], tc[3];
-    for (int s = 0; s < 3; ++s) {
-        int task = t + s * kThreads;
-        tc[s] = task / kGram;                  // camera; 2: no task
-        int e = task % kGram, a = 0;
-        while (e >= 16 - a) { e -= 16 - a; ++a; }
-        ta[s] = a; tb[s] = a + e;
-        if (tc[s] > (stereo ? 1 : 0)) tc[s] = 2;
-    }
-
-    for (int c0 = 0; c0 < C; c0 += kThreads) {
-        const int j = c0 + t;
+    const double *obs = cam == 0 ? left_xy : right_xy;
+    const double *ip = params + cam * nI;
+    double *st = stage[cam];
+    v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int j = c0 + lane;
+        double u0[16], u1[16];
         if (j < C) {
             const double wx = world_xy[2 * j], wy = world_xy[2 * j + 1];
             const size_t o = 2 * ((size_t)view * C + j);
-            rows_for(params, k, &ext[0][0], wx, wy, left_xy[o], left_xy[o + 1], rows[t][0][0],
-                     rows[t][0][1]);
-            if (stereo)
-                rows_for(params + nI, k, &ext[1][0], wx, wy, right_xy[o], right_xy[o + 1],
-                         rows[t][1][0], rows[t][1][1]);
+            rows_for<K>(ip, &ext[cam][0], wx, wy, obs[o], obs[o + 1], u0, u1);
             if (residual) {
                 if (stereo) {
-                    residual[o] = rows[t][0][0][15];
-                    residual[o + 1] = rows[t][0][1][15];
-                    residual[2 * (size_t)V * C + o] = rows[t][1][0][15];
-                    residual[2 * (size_t)V * C + o + 1] = rows[t][1][1][15];
+                    residual[(size_t)cam * 2 * V * C + o] = u0[15];
+                    residual[(size_t)cam * 2 * V * C + o + 1] = u1[15];
                 } else {
-                    residual[o] = -rows[t][0][0][15];
-                    residual[o + 1] = -rows[t][0][1][15];
+                    residual[o] = -u0[15];
+                    residual[o + 1] = -u1[15];
                 }
             }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { u0[q] = 0.0; u1[q] = 0.0; }
         }
-        __syncthreads();
-        const int cnt = min(kThreads, C - c0);
-        for (int s = 0; s < 3; ++s) {
-            if (tc[s] == 2) continue;
-            double acc = sum[s];
-            for (int jj = 0; jj < cnt; ++jj) {
-                acc += rows[jj][tc[s]][0][ta[s]] * rows[jj][tc[s]][0][tb[s]];
-                acc += rows[jj][tc[s]][1][ta[s]] * rows[jj][tc[s]][1][tb[s]];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) st[lane * kStageStride + q] = half ? u1[q] : u0[q];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                // A[row = lane & 15][k = lane >> 4] and B[k][col = lane & 15] are the same number
+                const double a = st[(4 * kk + (lane >> 4)) * kStageStride + (lane & 15)];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
             }
-            sum[s] = acc;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
     }
-    for (int s = 0; s < 3; ++s)
-        if (tc[s] != 2)
-            gram_view[((size_t)view * 2 + tc[s]) * kGram + (t + s * kThreads) % kGram] = sum[s];
+    // result (row = (lane >> 4) + 4 reg, col = lane & 15); keep the upper triangle
+    double *out = gram_view + ((size_t)view * 2 + cam) * kGram;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int row = (lane >> 4) + 4 * reg, col = lane & 15;
+        if (row <= col) out[row * 16 - (row * (row - 1)) / 2 + (col - row)] = acc[reg];
+    }
 }
 
 // Sums the per-view Gram matrices over the views: out[camera][136].
