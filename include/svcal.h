@@ -11,6 +11,8 @@
  *       jacobian Calibration/CStereoCameraCalibration.cpp:81-247 (+ J^T J, J^T e of :274-276)
  *   CMonocularCameraCalibration::refineAllPara
  *       value2 / residual2 / jacobian2  Calibration/CMonocularCameraCalibration.cpp:737-906
+ *   CStereoCameraRectification::doImageRectify
+ *       the per-pixel map loop           Calibration/CStereoCameraRectification.cpp:60-143
  * The reference forms the dense Jacobian (rows x (8 + 2k + 6V + 6)); here only its
  * non-zero blocks are evaluated and J^T J is returned block by block.
  *
@@ -81,6 +83,23 @@ int svcal_set_stream(svcal_ctx *ctx, void *hip_stream, int use_own);
  * of the whole problem and the per-view blocks (LE, EE, gE) of this context's views. */
 int svcal_shard_export(svcal_ctx *ctx, double *dev_sums272);
 int svcal_shard_import(svcal_ctx *ctx, const double *dev_sums272);
+
+/* CStereoCameraRectification::doImageRectify
+ * (Calibration/CStereoCameraRectification.cpp:60-143): for every pixel (i, j) of the
+ * rectified image, the position in the original left / right image to sample:
+ * inverse(proj) * (i, j, 1), normalise, distort (k_size 2 or 5 terms, :86-97), apply the
+ * 3x3 intrinsic matrix K (row-major, K[1] is the skew the reference multiplies in at
+ * :98); positions outside [0, width-1] x [0, height-1] become INVALID_MAP = 9.99e+04
+ * (Common/Utils.hpp:16).  Outputs: four host arrays of width * height doubles, row-major,
+ * as the reference allocates them (:70-73).  Needs a context only for its device and
+ * stream (no observations).  kernel_ms (may be NULL): device time of the map kernel.
+ * SVICP_ERR_ARG on the argument errors of :68-69, SVICP_ERR_SINGULAR for a singular
+ * projection. */
+int svcal_rectify_maps(svcal_ctx *ctx, int width, int height, const double KL[9],
+                       const double *distL, const double KR[9], const double *distR, int k_size,
+                       const double projL[9], const double projR[9], double *xmap_left,
+                       double *ymap_left, double *xmap_right, double *ymap_right,
+                       double *kernel_ms);
 
 /* Average duration (ms) of `reps` back-to-back svcal_eval launches. */
 int svcal_time_eval(svcal_ctx *ctx, int reps, double *avg_ms);

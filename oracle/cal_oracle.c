@@ -336,3 +336,139 @@ void orc_mono_residual_jacobian_dense(const double *vec, int V, int C, const dou
     }
     free(E);
 }
+
+/* ---- rectification (Calibration/CStereoCameraRectification.cpp) ---------------------- */
+
+/* General 3x3 inverse by Gaussian elimination with partial pivoting (the reference calls
+ * Eigen's dynamic-size inverse(), a partial-pivot LU).  Returns 0 if singular. */
+static int inv3(const double A[9], double out[9])
+{
+    double M[3][6];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 6; ++c) M[r][c] = c < 3 ? A[3 * r + c] : (c - 3 == r ? 1.0 : 0.0);
+    for (int c = 0; c < 3; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 3; ++r) if (fabs(M[r][c]) > fabs(M[p][c])) p = r;
+        if (M[p][c] == 0.0) return 0;
+        if (p != c) for (int k = 0; k < 6; ++k) { double t = M[c][k]; M[c][k] = M[p][k]; M[p][k] = t; }
+        for (int r = 0; r < 3; ++r) {
+            if (r == c) continue;
+            double f = M[r][c] / M[c][c];
+            for (int k = 0; k < 6; ++k) M[r][k] -= f * M[c][k];
+        }
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) out[3 * r + c] = M[r][3 + c] / M[r][r];
+    return 1;
+}
+
+/* Rotation matrix -> rotation vector, the branch of rodriguesTransform at
+ * CStereoCameraRectification.cpp:170-207 (the SVD polish U V^T of :172-173 is the identity
+ * map on a matrix that already is a rotation and is left out). */
+static void rot_to_vec(const double R[9], double r[3])
+{
+    r[0] = R[7] - R[5]; r[1] = R[2] - R[6]; r[2] = R[3] - R[1];
+    double s = sqrt((r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1.0e-5) {
+        if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
+        double t = (R[0] + 1) * 0.5;
+        r[0] = sqrt(t > 0 ? t : 0.);
+        t = (R[4] + 1) * 0.5;
+        r[1] = sqrt(t > 0 ? t : 0.) * (R[1] < 0 ? -1. : 1.);
+        t = (R[8] + 1) * 0.5;
+        r[2] = sqrt(t > 0 ? t : 0.) * (R[2] < 0 ? -1. : 1.);
+        if (fabs(r[0]) < fabs(r[1]) && fabs(r[0]) < fabs(r[2]) && (R[5] > 0) != (r[1] * r[2] > 0)) r[2] = -r[2];
+        theta /= sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        for (int k = 0; k < 3; ++k) r[k] *= theta;
+    } else {
+        double vth = 1 / (2 * s);
+        vth *= theta;
+        for (int k = 0; k < 3; ++k) r[k] *= vth;
+    }
+}
+
+static void mat3mul(const double A[9], const double B[9], double C[9])
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += A[3 * i + k] * B[3 * k + j];
+            C[3 * i + j] = s;
+        }
+}
+
+/* doStereoRectify (:13-58): half rotations, rectifying basis from the baseline, shared
+ * new intrinsics, Q.  All matrices row-major. */
+int orc_stereo_rectify(const double KL[9], const double KR[9], const double R_in[9],
+                       const double T_in[3], double projL[9], double projR[9], double Q[16])
+{
+    double Rinv[9], eul[3], half[9], peer[9], t[3], rect[9], tmp[9];
+    if (!inv3(R_in, Rinv)) return 0;                                    /* :21 */
+    rot_to_vec(Rinv, eul);                                              /* :22 */
+    for (int k = 0; k < 3; ++k) eul[k] *= -0.5;                         /* :23 */
+    orc_rodrigues(eul, half);                                           /* :24 */
+    mat3mul(half, Rinv, peer);                                          /* :25 */
+    for (int i = 0; i < 3; ++i)                                         /* :26 */
+        t[i] = -(peer[3 * i] * T_in[0] + peer[3 * i + 1] * T_in[1] + peer[3 * i + 2] * T_in[2]);
+    double n1 = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    double e1[3] = { t[0] / n1, t[1] / n1, t[2] / n1 };                 /* :28-29 */
+    double n2 = sqrt(t[0] * t[0] + t[1] * t[1]);
+    double e2[3] = { -t[1] / n2, t[0] / n2, 0 / n2 };                   /* :30-31 */
+    double e3[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2],
+                     e1[0] * e2[1] - e1[1] * e2[0] };                   /* :32 */
+    for (int k = 0; k < 3; ++k) { rect[k] = e1[k]; rect[3 + k] = e2[k]; rect[6 + k] = e3[k]; }
+    double Tx = rect[0] * t[0] + rect[1] * t[1] + rect[2] * t[2];       /* :39 */
+    double newK[9] = { (KL[0] + KL[4] + KR[0] + KR[4]) * 0.25, 0, (KL[2] + KR[2]) * 0.5,
+                       0, 0, (KL[5] + KR[5]) * 0.5, 0, 0, 1 };          /* :41-47 */
+    newK[4] = newK[0];
+    mat3mul(rect, half, tmp); mat3mul(newK, tmp, projL);                /* :37, :48 */
+    mat3mul(rect, peer, tmp); mat3mul(newK, tmp, projR);                /* :38, :49 */
+    for (int k = 0; k < 16; ++k) Q[k] = (k % 5 == 0) ? 1.0 : 0.0;       /* :50-56 */
+    Q[3] = -newK[2]; Q[7] = -newK[5]; Q[10] = 0; Q[11] = newK[0]; Q[14] = -1.0 / Tx; Q[15] = 0;
+    return 1;
+}
+
+static void rectify_one(const double K[9], const double *d, int k, const double Pinv[9],
+                        int w, int h, double *xmap, double *ymap)
+{
+    for (int j = 0; j < h; ++j)
+        for (int i = 0; i < w; ++i) {
+            double t0 = Pinv[0] * i + Pinv[1] * j + Pinv[2] * 1.0;      /* :81-82 */
+            double t1 = Pinv[3] * i + Pinv[4] * j + Pinv[5] * 1.0;
+            double t2 = Pinv[6] * i + Pinv[7] * j + Pinv[8] * 1.0;
+            double nx = t0 / t2, ny = t1 / t2;                          /* :83-84 */
+            double r = nx * nx + ny * ny, xe, ye;
+            if (k == 2) {                                               /* :86-97 */
+                xe = nx * (1.0 + d[0] * r + d[1] * r * r);
+                ye = ny * (1.0 + d[0] * r + d[1] * r * r);
+            } else {
+                xe = nx * (1.0 + d[0] * r + d[1] * r * r + d[4] * r * r * r) + 2.0 * d[2] * nx * ny +
+                     d[3] * (r * r + 2.0 * nx * nx);
+                ye = ny * (1.0 + d[0] * r + d[1] * r * r + d[4] * r * r * r) + 2.0 * d[3] * nx * ny +
+                     d[2] * (r * r + 2.0 * ny * ny);
+            }
+            double tx = K[0] * xe + K[1] * ye + K[2];                   /* :98-99 */
+            double ty = K[4] * ye + K[5];
+            int ok = tx >= 0 && ty >= 0 && tx <= w - 1 && ty <= h - 1;  /* :100 */
+            xmap[(size_t)j * w + i] = ok ? tx : 9.99e+04;               /* INVALID_MAP, Common/Utils.hpp:16 */
+            ymap[(size_t)j * w + i] = ok ? ty : 9.99e+04;
+        }
+}
+
+/* doImageRectify (:60-143): for every pixel of the rectified image, where to sample the
+ * original left / right image.  Returns 0 on the argument errors of :68-69 or a singular
+ * projection. */
+int orc_rectify_maps(int w, int h, const double KL[9], const double *dL, const double KR[9],
+                     const double *dR, int k, const double projL[9], const double projR[9],
+                     double *xl, double *yl, double *xr, double *yr)
+{
+    if (w <= 0 || h <= 0 || !(k == 2 || k == 5)) return 0;
+    double PL[9], PR[9];
+    if (!inv3(projL, PL) || !inv3(projR, PR)) return 0;
+    rectify_one(KL, dL, k, PL, w, h, xl, yl);
+    rectify_one(KR, dR, k, PR, w, h, xr, yr);
+    return 1;
+}

@@ -262,3 +262,27 @@ def icp_point2point(tree, src, iters, faithful=True, threads=1, history=True):
                                _d(info), 1 if faithful else 0, threads)
     return dict(rc=rc, trans=trans.reshape(4, 4), RT=RT, W=W.reshape(iters, 3, 3), info=info,
                 idx=idx, d2=d2, src=src)
+
+
+# ---------------------------------------------------------------- rectification
+def stereo_rectify(KL, KR, R, T):
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.orc_stereo_rectify.restype = C.c_int
+    L.orc_stereo_rectify.argtypes = [dp] * 7
+    a = [_dd(x).ravel() for x in (KL, KR, R, T)]
+    pl, pr, Q = np.empty(9), np.empty(9), np.empty(16)
+    ok = L.orc_stereo_rectify(_d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(pl), _d(pr), _d(Q))
+    return ok, pl.reshape(3, 3), pr.reshape(3, 3), Q.reshape(4, 4)
+
+
+def rectify_maps(w, h, KL, dL, KR, dR, projL, projR):
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.orc_rectify_maps.restype = C.c_int
+    L.orc_rectify_maps.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, C.c_int, dp, dp, dp, dp, dp, dp]
+    a = [_dd(x).ravel() for x in (KL, dL, KR, dR, projL, projR)]
+    maps = [np.empty((h, w)) for _ in range(4)]
+    ok = L.orc_rectify_maps(w, h, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), len(a[1]), _d(a[4]),
+                            _d(a[5]), *[_d(m) for m in maps])
+    return ok, maps

@@ -37,6 +37,8 @@ CAL_SYMBOLS = {
     "svcal_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "svcal_shard_export": (C.c_int, [C.c_void_p, C.c_void_p]),
     "svcal_shard_import": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "svcal_rectify_maps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp,
+                                     _dp, _dp, _dp, _dp, _dp]),
 }
 
 
@@ -316,3 +318,48 @@ def evaluate_sharded(engine, params, k, V_total, begin, end, group=None, fetch=T
         dist.all_reduce(t, group=group)
     engine.import_sums(t)
     return engine.fetch() if fetch else None
+
+
+def stereo_rectify(KL, KR, R, T):
+    """CStereoCameraRectification::doStereoRectify (CStereoCameraRectification.cpp:13-58) on the
+    host (a few 3 x 3 products): returns (left_proj, right_proj, Q)."""
+    from scipy.spatial.transform import Rotation
+    KL, KR = np.asarray(KL, np.float64).reshape(3, 3), np.asarray(KR, np.float64).reshape(3, 3)
+    Rinv = np.linalg.inv(np.asarray(R, np.float64).reshape(3, 3))
+    half = Rotation.from_rotvec(-0.5 * Rotation.from_matrix(Rinv).as_rotvec()).as_matrix()
+    peer = half @ Rinv
+    t = -peer @ np.asarray(T, np.float64).reshape(3)
+    e1 = t / np.linalg.norm(t)
+    e2 = np.array([-t[1], t[0], 0.0]) / np.hypot(t[0], t[1])
+    rect = np.stack([e1, e2, np.cross(e1, e2)])
+    f = (KL[0, 0] + KL[1, 1] + KR[0, 0] + KR[1, 1]) * 0.25
+    newK = np.array([[f, 0, (KL[0, 2] + KR[0, 2]) * 0.5], [0, f, (KL[1, 2] + KR[1, 2]) * 0.5], [0, 0, 1.0]])
+    Q = np.eye(4)
+    Q[0, 3], Q[1, 3], Q[2, 2], Q[2, 3] = -newK[0, 2], -newK[1, 2], 0.0, f
+    Q[3, 2], Q[3, 3] = -1.0 / float((rect @ t)[0]), 0.0
+    return newK @ rect @ half, newK @ rect @ peer, Q
+
+
+def rectify_maps(width, height, KL, distL, KR, distR, projL, projR, device=0, return_ms=False):
+    """CStereoCameraRectification::doImageRectify on the GPU: returns (xmap_left, ymap_left,
+    xmap_right, ymap_right), each (height, width) float64, INVALID_MAP = 9.99e4 outside."""
+    lib = _load()
+    h = C.c_void_p()
+    rc = lib.svcal_create(int(device), C.byref(h))
+    if rc != 0:
+        raise SvicpError(rc, lib.svcal_last_error(None).decode())
+    try:
+        arr = [np.ascontiguousarray(a, np.float64).ravel() for a in (KL, distL, KR, distR, projL, projR)]
+        k = len(arr[1])
+        if len(arr[3]) != k:
+            raise ValueError("both cameras need the same number of distortion terms")
+        maps = [np.empty((int(height), int(width)), np.float64) for _ in range(4)]
+        ms = C.c_double()
+        rc = lib.svcal_rectify_maps(h, int(width), int(height), _d(arr[0]), _d(arr[1]), _d(arr[2]),
+                                    _d(arr[3]), k, _d(arr[4]), _d(arr[5]), *[_d(m) for m in maps],
+                                    C.byref(ms))
+        if rc != 0:
+            raise SvicpError(rc, lib.svcal_last_error(h).decode())
+    finally:
+        lib.svcal_destroy(h)
+    return (*maps, ms.value) if return_ms else tuple(maps)

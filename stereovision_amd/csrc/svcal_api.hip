@@ -249,6 +249,78 @@ int svcal_shard_import(svcal_ctx *ctx, const double *dev_sums272)
     return SVICP_OK;
 }
 
+namespace {
+// general 3x3 inverse, Gaussian elimination with partial pivoting (the reference calls
+// Eigen's dynamic-size inverse() per pixel, CStereoCameraRectification.cpp:82, :111)
+bool invert3(const double A[9], double out[9])
+{
+    double M[3][6];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 6; ++c) M[r][c] = c < 3 ? A[3 * r + c] : (c - 3 == r ? 1.0 : 0.0);
+    for (int c = 0; c < 3; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 3; ++r) if (std::fabs(M[r][c]) > std::fabs(M[p][c])) p = r;
+        if (M[p][c] == 0.0) return false;
+        if (p != c) for (int k = 0; k < 6; ++k) std::swap(M[c][k], M[p][k]);
+        for (int r = 0; r < 3; ++r) {
+            if (r == c) continue;
+            const double f = M[r][c] / M[c][c];
+            for (int k = 0; k < 6; ++k) M[r][k] -= f * M[c][k];
+        }
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) out[3 * r + c] = M[r][3 + c] / M[r][r];
+    return true;
+}
+}  // namespace
+
+int svcal_rectify_maps(svcal_ctx *ctx, int width, int height, const double KL[9], const double *distL,
+                       const double KR[9], const double *distR, int k_size, const double projL[9],
+                       const double projR[9], double *xmap_left, double *ymap_left,
+                       double *xmap_right, double *ymap_right, double *kernel_ms)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (width <= 0 || height <= 0 || !(k_size == 2 || k_size == 5) || !KL || !KR || !distL || !distR ||
+        !projL || !projR || !xmap_left || !ymap_left || !xmap_right || !ymap_right)
+        return cfail(ctx, SVICP_ERR_ARG, "svcal_rectify_maps: bad argument");
+    RectifyCam L{}, R{};
+    for (int k = 0; k < 9; ++k) { L.K[k] = KL[k]; R.K[k] = KR[k]; }
+    for (int k = 0; k < k_size; ++k) { L.d[k] = distL[k]; R.d[k] = distR[k]; }
+    if (!invert3(projL, L.Pinv) || !invert3(projR, R.Pinv))
+        return cfail(ctx, SVICP_ERR_SINGULAR, "svcal_rectify_maps: a projection matrix is singular");
+    CHK(hipSetDevice(ctx->device));
+    const size_t px = (size_t)width * height, bytes = sizeof(double) * px;
+    double *dev = nullptr;
+    CHK(hipMalloc((void **)&dev, 4 * bytes));
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    const dim3 grid((unsigned)((px + 255) / 256)), block(256);
+    CHK(hipEventRecord(e0, ctx->stream));
+    if (k_size == 5)
+        hipLaunchKernelGGL(rectify_maps_kernel<5>, grid, block, 0, ctx->stream, L, R, width, height,
+                           dev, dev + px, dev + 2 * px, dev + 3 * px);
+    else
+        hipLaunchKernelGGL(rectify_maps_kernel<2>, grid, block, 0, ctx->stream, L, R, width, height,
+                           dev, dev + px, dev + 2 * px, dev + 3 * px);
+    hipError_t le = hipGetLastError();
+    CHK(hipEventRecord(e1, ctx->stream));
+    if (le == hipSuccess) le = hipMemcpyAsync(xmap_left, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(ymap_left, dev + px, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(xmap_right, dev + 2 * px, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (le == hipSuccess) le = hipMemcpyAsync(ymap_right, dev + 3 * px, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t se = hipStreamSynchronize(ctx->stream);
+    float ms = 0.f;
+    if (le == hipSuccess && se == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    if (kernel_ms) *kernel_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(dev);
+    if (le != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "svcal_rectify_maps", le);
+    if (se != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "svcal_rectify_maps", se);
+    return SVICP_OK;
+}
+
 int svcal_time_eval(svcal_ctx *ctx, int reps, double *avg_ms)
 {
     if (!ctx || !avg_ms || reps < 1) return cfail(ctx, SVICP_ERR_ARG, "svcal_time_eval: bad argument");

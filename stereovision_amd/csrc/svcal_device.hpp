@@ -248,4 +248,58 @@ __global__ __launch_bounds__(256) void cal_reduce_kernel(const double *__restric
     if (threadIdx.x == 0) gram_sum[task] = red[0];
 }
 
+// doImageRectify (CStereoCameraRectification.cpp:60-143): one thread per pixel of the
+// rectified image and both cameras; writes where to sample the original images, or
+// INVALID_MAP (Common/Utils.hpp:16) outside them.  Pinv = inverse of the 3x3 projection.
+struct RectifyCam {
+    double K[9];
+    double d[5];
+    double Pinv[9];
+};
+
+template <int K>
+__device__ __forceinline__ void rectify_pixel(const RectifyCam &c, int i, int j, int w, int h,
+                                              double &mx, double &my)
+{
+    const double t0 = c.Pinv[0] * i + c.Pinv[1] * j + c.Pinv[2] * 1.0;
+    const double t1 = c.Pinv[3] * i + c.Pinv[4] * j + c.Pinv[5] * 1.0;
+    const double t2 = c.Pinv[6] * i + c.Pinv[7] * j + c.Pinv[8] * 1.0;
+    const double nx = t0 / t2, ny = t1 / t2;
+    const double r = nx * nx + ny * ny;
+    double xe, ye;
+    if (K == 2) {
+        xe = nx * (1.0 + c.d[0] * r + c.d[1] * r * r);
+        ye = ny * (1.0 + c.d[0] * r + c.d[1] * r * r);
+    } else {
+        // the order of the two tangential terms of ye is that of :95-96, not that of the
+        // calibration's value()
+        xe = nx * (1.0 + c.d[0] * r + c.d[1] * r * r + c.d[4] * r * r * r) + 2.0 * c.d[2] * nx * ny +
+             c.d[3] * (r * r + 2.0 * nx * nx);
+        ye = ny * (1.0 + c.d[0] * r + c.d[1] * r * r + c.d[4] * r * r * r) + 2.0 * c.d[3] * nx * ny +
+             c.d[2] * (r * r + 2.0 * ny * ny);
+    }
+    const double tx = c.K[0] * xe + c.K[1] * ye + c.K[2];
+    const double ty = c.K[4] * ye + c.K[5];
+    const bool ok = tx >= 0 && ty >= 0 && tx <= w - 1 && ty <= h - 1;
+    mx = ok ? tx : 9.99e+04;
+    my = ok ? ty : 9.99e+04;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void rectify_maps_kernel(RectifyCam L, RectifyCam R, int w, int h,
+                                                           double *__restrict__ xl,
+                                                           double *__restrict__ yl,
+                                                           double *__restrict__ xr,
+                                                           double *__restrict__ yr)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long long)w * h) return;
+    const int j = (int)(p / w), i = (int)(p - (long long)j * w);
+    double a, b;
+    rectify_pixel<K>(L, i, j, w, h, a, b);
+    xl[p] = a; yl[p] = b;
+    rectify_pixel<K>(R, i, j, w, h, a, b);
+    xr[p] = a; yr[p] = b;
+}
+
 }  // namespace svcal

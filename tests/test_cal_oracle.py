@@ -137,3 +137,60 @@ def test_block_sparse_solve_equals_dense_solve(po):
     step, _ = solve_damped(blocks, 5, 4, 1e-3, stereo=False)
     ref = -np.linalg.solve(A + 1e-3 * np.diag(np.diag(A)), G)
     assert np.abs(step - ref).max() < 1e-9 * np.abs(ref).max()
+
+
+# ---- rectification (CStereoCameraRectification.cpp) -----------------------------
+def _stereo_rig():
+    KL = np.array([[535.0, 0, 322.0], [0, 537.0, 243.0], [0, 0, 1]])
+    KR = np.array([[533.0, 0, 318.0], [0, 534.0, 239.0], [0, 0, 1]])
+    dL = np.array([-0.28, 0.09, 1e-3, -5e-4, 0.01])
+    dR = np.array([-0.27, 0.08, -7e-4, 4e-4, -0.02])
+    R = Rotation.from_rotvec([0.01, -0.02, 0.005]).as_matrix()
+    T = np.array([-90.0, 1.0, 2.0])
+    return KL, dL, KR, dR, R, T
+
+
+def test_stereo_rectify_against_numpy_and_its_properties(po):
+    from stereovision_amd.calib import stereo_rectify
+    KL, dL, KR, dR, R, T = _stereo_rig()
+    ok, pl, pr, Q = po.stereo_rectify(KL, KR, R, T)
+    assert ok
+    npl, npr, nQ = stereo_rectify(KL, KR, R, T)
+    assert np.allclose(pl, npl, atol=1e-9) and np.allclose(pr, npr, atol=1e-9)
+    assert np.allclose(Q, nQ, atol=1e-12)
+    # both projections share the new intrinsics; what is left of each is a rotation, and the
+    # two rotations differ by the rig's rotation (CStereoCameraRectification.cpp:21-38)
+    newK = np.array([[534.75, 0, 320.0], [0, 534.75, 241.0], [0, 0, 1]])
+    RL, RR = np.linalg.inv(newK) @ pl, np.linalg.inv(newK) @ pr
+    assert np.allclose(RL @ RL.T, np.eye(3), atol=1e-12) and np.allclose(RR @ RR.T, np.eye(3), atol=1e-12)
+    assert np.allclose(RR, RL @ np.linalg.inv(R), atol=1e-12)
+    # the rectified baseline lies along x: Q(3,2) = -1/Tx with |Tx| the baseline length
+    assert abs(abs(1.0 / Q[3, 2]) - np.linalg.norm(T)) < 1e-9
+
+
+def test_rectify_maps_properties(po):
+    from stereovision_amd.calib import stereo_rectify
+    KL, dL, KR, dR, R, T = _stereo_rig()
+    pl, pr, _ = stereo_rectify(KL, KR, R, T)
+    ok, (xl, yl, xr, yr) = po.rectify_maps(640, 480, KL, dL, KR, dR, pl, pr)
+    assert ok
+    # independent numpy evaluation of one pixel (CStereoCameraRectification.cpp:81-99)
+    i, j = 400, 200
+    t = np.linalg.inv(pl) @ np.array([i, j, 1.0])
+    nx, ny = t[0] / t[2], t[1] / t[2]
+    r = nx * nx + ny * ny
+    rad = 1.0 + dL[0] * r + dL[1] * r * r + dL[4] * r * r * r
+    xe = nx * rad + 2.0 * dL[2] * nx * ny + dL[3] * (r * r + 2.0 * nx * nx)
+    ye = ny * rad + 2.0 * dL[3] * nx * ny + dL[2] * (r * r + 2.0 * ny * ny)
+    assert xl[j, i] == pytest.approx(KL[0, 0] * xe + KL[0, 2], abs=1e-9)
+    assert yl[j, i] == pytest.approx(KL[1, 1] * ye + KL[1, 2], abs=1e-9)
+    # out-of-image samples are flagged in both maps at once (:100-110)
+    shift = np.array([[1.0, 0, 80.0], [0, 1, 0], [0, 0, 1]])        # rectified image moved right
+    ok, (xl, yl, _, _) = po.rectify_maps(640, 480, KL, dL, KR, dR, shift @ pl, pr)
+    bad = xl == 9.99e4
+    assert np.array_equal(bad, yl == 9.99e4)
+    assert bad.any() and not bad.all() and bad[240, 0] and not bad[240, 320]
+    assert np.all(xl[~bad] >= 0) and np.all(xl[~bad] <= 639) and np.all(yl[~bad] <= 479)
+    # argument errors of :68-69
+    assert not po.rectify_maps(0, 48, KL, dL, KR, dR, pl, pr)[0]
+    assert not po.rectify_maps(8, 8, KL, dL[:3], KR, dR[:3], pl, pr)[0]

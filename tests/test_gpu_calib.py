@@ -159,3 +159,40 @@ def test_dense_and_block_sparse_loops_agree(po):
     # observable), so the iterates drift apart in the eighth digit of the error
     assert ea == pytest.approx(eb, rel=1e-6)
     assert np.abs(xa[:4] - xb[:4]).max() < 1e-2 and np.abs(xa[-3:] - xb[-3:]).max() < 1e-2
+
+
+# ---- rectification maps (CStereoCameraRectification::doImageRectify) -----------
+@pytest.mark.parametrize("size,k", [((640, 480), 5), ((640, 480), 2), ((1921, 1083), 5)])
+def test_rectify_maps_match_oracle(po, size, k):
+    """Same operations in fp64 on both sides; the inverse of the projection is formed by the
+    same elimination.  Tolerance 1e-9 pixel; the in/out-of-image decision may flip only for
+    samples within that distance of the border."""
+    from scipy.spatial.transform import Rotation
+    from stereovision_amd.calib import rectify_maps, stereo_rectify
+    KL = np.array([[535.0, 0.3, 322.0], [0, 537.0, 243.0], [0, 0, 1]])   # with a little skew
+    KR = np.array([[533.0, 0, 318.0], [0, 534.0, 239.0], [0, 0, 1]])
+    dL = np.array([-0.28, 0.09, 1e-3, -5e-4, 0.01])[:k]
+    dR = np.array([-0.27, 0.08, -7e-4, 4e-4, -0.02])[:k]
+    R = Rotation.from_rotvec([0.01, -0.02, 0.005]).as_matrix()
+    pl, pr, _ = stereo_rectify(KL, KR, R, [-90.0, 1.0, 2.0])
+    w, h = size
+    got = rectify_maps(w, h, KL, dL, KR, dR, pl, pr)
+    ok, want = po.rectify_maps(w, h, KL, dL, KR, dR, pl, pr)
+    assert ok
+    for g, e in zip(got, want):
+        differ = (g == 9.99e4) != (e == 9.99e4)
+        assert differ.sum() <= 4
+        assert np.abs(g - e)[~differ].max() < 1e-9
+    assert (got[0] != 9.99e4).mean() > 0.5
+
+
+def test_rectify_maps_argument_errors():
+    from stereovision_amd import SvicpError
+    from stereovision_amd.calib import rectify_maps
+    K = np.eye(3)
+    with pytest.raises(SvicpError):
+        rectify_maps(0, 10, K, np.zeros(5), K, np.zeros(5), K, K)
+    with pytest.raises(SvicpError):
+        rectify_maps(10, 10, K, np.zeros(3), K, np.zeros(3), K, K)
+    with pytest.raises(SvicpError):
+        rectify_maps(10, 10, K, np.zeros(5), K, np.zeros(5), np.zeros((3, 3)), K)
