@@ -129,6 +129,20 @@ def main():
         with open(tpath) as fh:
             traffic = json.load(fh).get("icp_iterate_kernel_bytes_per_launch")
 
+    # ---- what this GPU's HBM delivers on a plain copy, for scale (torch is plumbing here:
+    # one large device-to-device copy, read + write counted) ----
+    a = torch.empty(1 << 28, dtype=torch.uint8, device=f"cuda:{local}")
+    b = torch.empty_like(a)
+    b.copy_(a)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        b.copy_(a)
+    ev1.record()
+    torch.cuda.synchronize()
+    stream_copy_gbs = 10 * 2.0 * a.numel() / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    del a, b
+
     # ---- sharded leg ----------------------------------------------------
     sharded = None
     if args.sharded_side > 0:
@@ -273,6 +287,16 @@ def main():
             "max_abs_X_diff_vs_gpu": float(np.abs(Xg[: args.cpu_iters] - r["X"]).max()),
         }
 
+    cpu_all = None
+    if cpu is not None:
+        threads = min(po.max_threads(), 16)
+        t0 = time.perf_counter()
+        po.icp_point2plane(tree, nrm, src, args.cpu_iters, faithful=True, threads=threads, history=False)
+        cpu_all = {"value": args.cpu_iters / (time.perf_counter() - t0), "unit": "iters/s",
+                   "cores": threads, "kind": "port",
+                   "sample": "as cpu_baseline, the nearest-neighbour queries spread over the host "
+                             "threads (the reference itself is single-threaded)"}
+
     if rank == 0:
         out = {
             "metric": "point-to-plane ICP iters/s at 1M pts",
@@ -300,11 +324,13 @@ def main():
                 "bytes_per_launch": bytes_fused, "launch_ms": fused_ms,
                 "launch_ms_between_events": raw_ms, "empty_event_pair_ms": pair_ms,
                 "launches_averaged": args.iters,
+                "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": achieved / stream_copy_gbs,
                 "loop_ms_per_iteration": elapsed / args.steps / args.iters * 1e3,
                 "slowest_launch_ms": slowest_ms,
                 "frac_slowest_launch": bytes_fused / (slowest_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
             "kernels_ms": {"icp_iterate": fused_ms,
                            "icp_iterate_per_iteration": [round(float(x), 5) for x in per_iter],
                            "nn1_capped": nn_capped_ms, "nn1_exact": nn_exact_ms},
