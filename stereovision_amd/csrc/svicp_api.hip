@@ -191,10 +191,9 @@ int run_knn(svicp_ctx *ctx, const float *q_aos, int64_t n, int k, int *idx, floa
         hipLaunchKernelGGL((knn_kernel<KM, false>), dim3(grid), dim3(kBlockThreads), 0,          \
                            ctx->stream, ctx->g, q_aos, (int)n, k, idx, d2, unres, nun);          \
         LAUNCHCHK("knn_kernel");                                                                 \
-        hipLaunchKernelGGL((knn_kernel<KM, true>), dim3(std::min(grid, 1024)),                   \
-                           dim3(kBlockThreads), 0, ctx->stream, ctx->g, q_aos, (int)n, k, idx,   \
-                           d2, unres, nun);                                                      \
-        LAUNCHCHK("knn_kernel(brute)");                                                          \
+        hipLaunchKernelGGL((knn_brute_block_kernel<KM>), dim3(2048), dim3(kBlockThreads), 0,     \
+                           ctx->stream, ctx->g, q_aos, k, idx, d2, unres, nun);                  \
+        LAUNCHCHK("knn_brute_block_kernel");                                                     \
     } while (0)
     if (k <= 8) KNN_LAUNCH(8);
     else if (k <= 32) KNN_LAUNCH(32);

@@ -26,6 +26,7 @@ constexpr int kNumSums = 32;   // 21 JtJ + 6 Jtr + inliers + sum w b^2 + sum w +
 constexpr int kDeltaCopies = 4;   // measured: 1 copy costs 9 us per search-heavy iteration, 16 slow the solve
 constexpr int kDeltaRow = kDeltaCopies * kNumSums;   // doubles per iteration
 constexpr int kMaxRing = 3;    // exact search: rings tried before the brute-force pass
+constexpr int kKnnMaxRing = 6; // the same for the k-NN facade, whose exhaustive pass costs more
 
 struct GridDesc {
     float ox, oy, oz;        // origin (one empty cell below the target's bounding box)
@@ -1069,7 +1070,7 @@ __global__ __launch_bounds__(kBlockThreads) void knn_kernel(
         } else {
             int cx, cy, cz;
             clamped_origin(g, qx, qy, qz, cx, cy, cz);
-            for (int ring = (k > 1 ? 1 : 0); ring <= kMaxRing; ++ring) {
+            for (int ring = (k > 1 ? 1 : 0); ring <= kKnnMaxRing; ++ring) {
                 int x0, x1, y0, y1, z0, z1;
                 float rho = ring_box(g, qx, qy, qz, cx, cy, cz, ring, x0, x1, y0, y1, z0, z1);
                 L.clear(k);
@@ -1091,6 +1092,54 @@ __global__ __launch_bounds__(kBlockThreads) void knn_kernel(
         } else {
             int slot = atomicAdd(n_unresolved, 1);
             unresolved[slot] = (int)i;
+        }
+    }
+}
+
+// Exhaustive pass of the k-NN for the queries the ring search could not settle: one
+// block per query.  Every thread keeps the k best of its share of the target; the k
+// answers are then drawn one at a time from the heads of the 256 sorted lists (block-wide
+// minimum of the (distance, index) keys, which are distinct).
+template <int KMAX>
+__global__ __launch_bounds__(kBlockThreads) void knn_brute_block_kernel(
+    GridDesc g, const float *__restrict__ q_aos, int k, int *__restrict__ idx_out,
+    float *__restrict__ d2_out, const int *__restrict__ unresolved,
+    const int *__restrict__ n_unresolved)
+{
+    __shared__ unsigned long long wave_min[kBlockThreads / 64];
+    const int cnt = *n_unresolved;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int u = blockIdx.x; u < cnt; u += gridDim.x) {
+        const long long i = unresolved[u];
+        const float qx = q_aos[3 * i], qy = q_aos[3 * i + 1], qz = q_aos[3 * i + 2];
+        KList<KMAX> L;
+        L.clear(k);
+        for (int j = threadIdx.x; j < g.m; j += kBlockThreads) {
+            const float4 p = g.pts[j];
+            L.insert(dist2(qx, qy, qz, p), __float_as_int(p.w));
+        }
+        int head = 0;
+        for (int r = 0; r < k; ++r) {
+            const unsigned long long mine =
+                head < L.cnt ? ((unsigned long long)__float_as_uint(L.d[head]) << 32) | (unsigned)L.id[head]
+                             : ~0ull;
+            unsigned long long m = mine;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(m, off, 64);
+                m = o < m ? o : m;
+            }
+            if (lane == 0) wave_min[wv] = m;
+            __syncthreads();
+            unsigned long long best = wave_min[0];
+#pragma unroll
+            for (int w = 1; w < kBlockThreads / 64; ++w) best = wave_min[w] < best ? wave_min[w] : best;
+            if (mine == best && best != ~0ull) ++head;
+            if (threadIdx.x == 0) {
+                idx_out[i * k + r] = best != ~0ull ? (int)(unsigned)best : -1;
+                d2_out[i * k + r] = best != ~0ull ? __uint_as_float((unsigned)(best >> 32)) : INFINITY;
+            }
+            __syncthreads();
         }
     }
 }
