@@ -28,6 +28,24 @@ struct svcal_ctx {
 namespace {
 thread_local std::string g_cal_create_error;
 
+// released on every path out of the scope that made them
+struct ScopedEvent {
+    hipEvent_t ev = nullptr;
+    hipError_t create() { return hipEventCreate(&ev); }
+    ~ScopedEvent() { if (ev) (void)hipEventDestroy(ev); }
+    ScopedEvent() = default;
+    ScopedEvent(const ScopedEvent &) = delete;
+    ScopedEvent &operator=(const ScopedEvent &) = delete;
+};
+struct ScopedDevice {
+    void *p = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    ~ScopedDevice() { if (p) (void)hipFree(p); }
+    ScopedDevice() = default;
+    ScopedDevice(const ScopedDevice &) = delete;
+    ScopedDevice &operator=(const ScopedDevice &) = delete;
+};
+
 int cfail(svcal_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
 {
     char buf[512];
@@ -290,34 +308,33 @@ int svcal_rectify_maps(svcal_ctx *ctx, int width, int height, const double KL[9]
         return cfail(ctx, SVICP_ERR_SINGULAR, "svcal_rectify_maps: a projection matrix is singular");
     CHK(hipSetDevice(ctx->device));
     const size_t px = (size_t)width * height, bytes = sizeof(double) * px;
-    double *dev = nullptr;
-    CHK(hipMalloc((void **)&dev, 4 * bytes));
-    hipEvent_t e0, e1;
-    CHK(hipEventCreate(&e0));
-    CHK(hipEventCreate(&e1));
+    ScopedDevice buf;
+    CHK(buf.alloc(4 * bytes));
+    double *dev = static_cast<double *>(buf.p);
+    ScopedEvent e0, e1;
+    CHK(e0.create());
+    CHK(e1.create());
     const dim3 grid((unsigned)((px + 255) / 256)), block(256);
-    CHK(hipEventRecord(e0, ctx->stream));
+    CHK(hipEventRecord(e0.ev, ctx->stream));
     if (k_size == 5)
         hipLaunchKernelGGL(rectify_maps_kernel<5>, grid, block, 0, ctx->stream, L, R, width, height,
                            dev, dev + px, dev + 2 * px, dev + 3 * px);
     else
         hipLaunchKernelGGL(rectify_maps_kernel<2>, grid, block, 0, ctx->stream, L, R, width, height,
                            dev, dev + px, dev + 2 * px, dev + 3 * px);
-    hipError_t le = hipGetLastError();
-    CHK(hipEventRecord(e1, ctx->stream));
-    if (le == hipSuccess) le = hipMemcpyAsync(xmap_left, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (le == hipSuccess) le = hipMemcpyAsync(ymap_left, dev + px, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (le == hipSuccess) le = hipMemcpyAsync(xmap_right, dev + 2 * px, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (le == hipSuccess) le = hipMemcpyAsync(ymap_right, dev + 3 * px, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    hipError_t se = hipStreamSynchronize(ctx->stream);
+    CHK(hipGetLastError());
+    CHK(hipEventRecord(e1.ev, ctx->stream));
+    double *outs[4] = { xmap_left, ymap_left, xmap_right, ymap_right };
+    hipError_t err = hipSuccess;
+    for (int q = 0; q < 4 && err == hipSuccess; ++q)
+        err = hipMemcpyAsync(outs[q], dev + q * px, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    // the copies already queued read the buffer: wait before it is released, whatever happened
+    const hipError_t sync = hipStreamSynchronize(ctx->stream);
+    if (err != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "svcal_rectify_maps: copy", err);
+    if (sync != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "svcal_rectify_maps: sync", sync);
     float ms = 0.f;
-    if (le == hipSuccess && se == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    CHK(hipEventElapsedTime(&ms, e0.ev, e1.ev));
     if (kernel_ms) *kernel_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(dev);
-    if (le != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "svcal_rectify_maps", le);
-    if (se != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "svcal_rectify_maps", se);
     return SVICP_OK;
 }
 
@@ -326,20 +343,18 @@ int svcal_time_eval(svcal_ctx *ctx, int reps, double *avg_ms)
     if (!ctx || !avg_ms || reps < 1) return cfail(ctx, SVICP_ERR_ARG, "svcal_time_eval: bad argument");
     int rc = svcal_eval(ctx);   // warm-up
     if (rc) return rc;
-    hipEvent_t a, b;
-    CHK(hipEventCreate(&a));
-    CHK(hipEventCreate(&b));
-    CHK(hipEventRecord(a, ctx->stream));
+    ScopedEvent a, b;
+    CHK(a.create());
+    CHK(b.create());
+    CHK(hipEventRecord(a.ev, ctx->stream));
     for (int r = 0; r < reps; ++r) {
         rc = svcal_eval(ctx);
         if (rc) return rc;
     }
-    CHK(hipEventRecord(b, ctx->stream));
-    CHK(hipEventSynchronize(b));
+    CHK(hipEventRecord(b.ev, ctx->stream));
+    CHK(hipEventSynchronize(b.ev));
     float ms = 0;
-    CHK(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    CHK(hipEventElapsedTime(&ms, a.ev, b.ev));
     *avg_ms = (double)ms / reps;
     return SVICP_OK;
 }

@@ -39,6 +39,16 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// an event that is destroyed on every path out of the scope that made it
+struct ScopedEvent {
+    hipEvent_t ev = nullptr;
+    hipError_t create() { return hipEventCreate(&ev); }
+    ~ScopedEvent() { if (ev) (void)hipEventDestroy(ev); }
+    ScopedEvent() = default;
+    ScopedEvent(const ScopedEvent &) = delete;
+    ScopedEvent &operator=(const ScopedEvent &) = delete;
+};
+
 }  // namespace
 
 struct svicp_ctx {
@@ -957,22 +967,20 @@ int svicp_time_nn(svicp_ctx *ctx, int exact, int reps, double *avg_ms)
     if (!ctx->have_target || !ctx->have_source)
         return fail(ctx, SVICP_ERR_ARG, "svicp_time_nn: set the target and the source first");
     HIPCHK(hipSetDevice(ctx->device));
-    hipEvent_t a, b;
-    HIPCHK(hipEventCreate(&a));
-    HIPCHK(hipEventCreate(&b));
+    ScopedEvent a, b;
+    HIPCHK(a.create());
+    HIPCHK(b.create());
     int rc = run_nn1(ctx, exact != 0);   // warm-up
     if (rc) return rc;
-    HIPCHK(hipEventRecord(a, ctx->stream));
+    HIPCHK(hipEventRecord(a.ev, ctx->stream));
     for (int r = 0; r < reps; ++r) {
         rc = run_nn1(ctx, exact != 0);
         if (rc) return rc;
     }
-    HIPCHK(hipEventRecord(b, ctx->stream));
-    HIPCHK(hipEventSynchronize(b));
+    HIPCHK(hipEventRecord(b.ev, ctx->stream));
+    HIPCHK(hipEventSynchronize(b.ev));
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    HIPCHK(hipEventElapsedTime(&ms, a.ev, b.ev));
     *avg_ms = (double)ms / reps;
     return SVICP_OK;
 }
@@ -1129,9 +1137,11 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
         svicp_ctx *c = b->ctxs[i];
         if (!c->have_target || !c->have_source)
             return fail(ctx, SVICP_ERR_ARG, "svicp_batch_run: a pair lost its target or source");
-        HIPCHK(hipStreamSynchronize(c->stream));     // set-up work of the pair is done
         int rc = ensure_iteration_buffers(c, iterations);
         if (rc) { ctx->err = c->err; return rc; }
+        // the pair's set-up work (and any clearing of fresh buffers just queued) ran on its
+        // own stream: it must be complete before the batch's stream touches the buffers
+        HIPCHK(hipStreamSynchronize(c->stream));
         const float thr = c->opt.dist_threshold;
         BatchPair &P = hp[i];
         P.g = c->g;
@@ -1186,10 +1196,10 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
         return SVICP_OK;
     };
 
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, ctx->stream));
+    ScopedEvent e0, e1;
+    HIPCHK(e0.create());
+    HIPCHK(e1.create());
+    HIPCHK(hipEventRecord(e0.ev, ctx->stream));
     if (ctx->opt.use_graph) {
         if (!b->gexec) {
             hipGraph_t graph = nullptr;
@@ -1208,14 +1218,12 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
         int rc = enqueue();
         if (rc) return rc;
     }
-    HIPCHK(hipEventRecord(e1, ctx->stream));
+    HIPCHK(hipEventRecord(e1.ev, ctx->stream));
     HIPCHK(hipMemcpyAsync(b->h_states, b->states.p, sizeof(IcpState) * count, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    HIPCHK(hipEventElapsedTime(&ms, e0.ev, e1.ev));
     b->last_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
 
     int worst = SVICP_OK;
     for (int i = 0; i < count; ++i) {
