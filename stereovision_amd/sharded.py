@@ -1,10 +1,11 @@
 """Registration of one large cloud pair sharded over ranks (one process per GPU).
 
 Every rank holds the whole target grid and a contiguous slice of the source.
-Per iteration each rank reduces its slice to 32 doubles (21 upper-triangle
-JtJ entries, 6 Jtr entries, 3 statistics, 2 pad), the ranks all-reduce that
-block (RCCL over xGMI when the process group's backend is "nccl"), and every
-rank solves the same 6x6 system, so no broadcast follows.  This is the only
+Per iteration each rank produces 32 doubles: the change its slice made to the
+sums of the normal equations (21 upper-triangle JtJ entries, 6 Jtr entries, 3
+statistics, 2 pad; the library keeps the running totals).  The ranks all-reduce
+that block (RCCL over xGMI when the process group's backend is "nccl"), and
+every rank solves the same 6x6 system, so no broadcast follows.  This is the only
 exchange step of CPoint2PlaneICP::singleRun (CPoint2PlaneICP.cpp:63-120);
 the reference itself is single-process.
 """
