@@ -76,14 +76,23 @@ def main():
     ctx.set_source(src)
 
     # ---- primary: K registrations of `iters` iterations each -------------
+    # The library launches on a torch stream here so that torch's events, recorded on that
+    # same stream, bracket exactly the launches of the timed region.
+    side = torch.cuda.Stream(device=f"cuda:{local}")
+    ctx.set_stream(side.cuda_stream)
     for _ in range(args.warmup):
         T, info = ctx.run(args.iters)
     barrier()
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev_a.record(side)
     for _ in range(args.steps):
         T, info = ctx.run(args.iters)
+    ev_b.record(side)
     barrier()
     elapsed = time.perf_counter() - t0
+    region_ms = ev_a.elapsed_time(ev_b)
+    launch_region_ms = region_ms / (args.steps * args.iters)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -109,7 +118,10 @@ def main():
     # algorithmic bytes of one launch of the iteration kernel: source read + write
     # (24 B/pt), target xyz + index + normal (28 B/pt), each touched once
     bytes_fused = 24.0 * n + 28.0 * len(tgt)
-    achieved = bytes_fused / (fused_ms * 1e-3) / 1e9
+    # the roofline figure uses the average over the timed region (events on the launch
+    # stream around all K x iters launches: gaps between launches and the one small solve
+    # launch that ends a step included); the per-launch event figures are kept beside it
+    achieved = bytes_fused / (launch_region_ms * 1e-3) / 1e9
     slowest_ms = float(per_iter.max())            # a launch that searches every point
     nn_capped_ms = ctx.time_nn(exact=False, reps=20)
     nn_exact_ms = ctx.time_nn(exact=True, reps=20)
@@ -321,9 +333,12 @@ def main():
                 "bound": "hbm", "kernel": "icp_iterate_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "bytes_per_launch": bytes_fused, "launch_ms": fused_ms,
-                "launch_ms_between_events": raw_ms, "empty_event_pair_ms": pair_ms,
-                "launches_averaged": args.iters,
+                "bytes_per_launch": bytes_fused, "launch_ms": launch_region_ms,
+                "launch_ms_method": "HIP events on the launch stream around the whole timed region "
+                                    "/ (steps x iterations)",
+                "eager_launch_ms_between_events": raw_ms, "empty_event_pair_ms": pair_ms,
+                "eager_launch_ms_minus_empty_pair": fused_ms,
+                "launches_averaged": args.steps * args.iters,
                 "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": achieved / stream_copy_gbs,
                 "loop_ms_per_iteration": elapsed / args.steps / args.iters * 1e3,
                 "slowest_launch_ms": slowest_ms,
