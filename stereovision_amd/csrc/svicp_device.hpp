@@ -25,8 +25,8 @@ constexpr int kNumSums = 32;   // 21 JtJ + 6 Jtr + inliers + sum w b^2 + sum w +
 // and the solve adds the copies up in a fixed order.
 constexpr int kDeltaCopies = 4;   // measured: 1 copy costs 9 us per search-heavy iteration, 16 slow the solve
 constexpr int kDeltaRow = kDeltaCopies * kNumSums;   // doubles per iteration
-constexpr int kMaxRing = 3;    // exact search: rings tried before the brute-force pass
-constexpr int kKnnMaxRing = 6; // the same for the k-NN facade, whose exhaustive pass costs more
+constexpr int kMaxRing = 8;    // exact search: rings tried before the brute-force pass
+constexpr int kKnnMaxRing = 8; // the same for the k-NN facade
 
 struct GridDesc {
     float ox, oy, oz;        // origin (one empty cell below the target's bounding box)
@@ -962,17 +962,33 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
         int cx, cy, cz;
         clamped_origin(g, qx, qy, qz, cx, cy, cz);
         bool done = false;
+        auto visit = [&](unsigned j) {
+            float4 p = g.pts[j];
+            float d = dist2(qx, qy, qz, p);
+            int id = __float_as_int(p.w);
+            if (better(d, id, best, bidx)) { best = d; bpos = (int)j; bidx = id; }
+        };
+        // the box of the previous ring (already scanned): empty before the first scan
+        int px0 = 0, px1 = -1, py0 = 0, py1 = -1, pz0 = 0, pz1 = -1;
         for (int ring = 0; ring <= kMaxRing; ++ring) {
             int x0, x1, y0, y1, z0, z1;
             float rho = ring_box(g, qx, qy, qz, cx, cy, cz, ring, x0, x1, y0, y1, z0, z1);
             if (ring > 0 || bpos < 0) {
-                // ring 0 was scanned by nn_capped unless the probe left the grid
-                scan_box(g, x0, x1, y0, y1, z0, z1, [&](unsigned j) {
-                    float4 p = g.pts[j];
-                    float d = dist2(qx, qy, qz, p);
-                    int id = __float_as_int(p.w);
-                    if (better(d, id, best, bidx)) { best = d; bpos = (int)j; bidx = id; }
-                });
+                // ring 0 was scanned by nn_capped unless the probe left the grid; later rings
+                // scan only the shell around the box already seen (the best so far carries over)
+                if (px1 < px0) {
+                    scan_box(g, x0, x1, y0, y1, z0, z1, visit);
+                } else {
+                    if (z0 < pz0) scan_box(g, x0, x1, y0, y1, z0, pz0 - 1, visit);
+                    if (z1 > pz1) scan_box(g, x0, x1, y0, y1, pz1 + 1, z1, visit);
+                    if (y0 < py0) scan_box(g, x0, x1, y0, py0 - 1, pz0, pz1, visit);
+                    if (y1 > py1) scan_box(g, x0, x1, py1 + 1, y1, pz0, pz1, visit);
+                    if (x0 < px0) scan_box(g, x0, px0 - 1, py0, py1, pz0, pz1, visit);
+                    if (x1 > px1) scan_box(g, px1 + 1, x1, py0, py1, pz0, pz1, visit);
+                }
+                px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;
+            } else {
+                px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;   // what nn_capped saw
             }
             if (rho == INFINITY || (bpos >= 0 && rho > 0.f && best <= rho * rho)) { done = true; break; }
         }
