@@ -97,34 +97,13 @@ __device__ __forceinline__ bool probe_origin(const GridDesc &g, float qx, float 
     return true;
 }
 
-// Nearest target point within the probe radius: the 1-NN the ICP loop needs.
-// best = +inf, bpos = -1 when the probed cells are empty.
-//
-// The four runs are walked as one flat candidate list, CH candidates at a
-// time: the CH loads of a chunk are issued together (one memory latency per
-// chunk instead of one per candidate) and a wave iterates max-over-lanes of
-// the TOTAL candidate count, not the sum of per-run maxima.
-template <int CH, bool SECOND = false>
-__device__ __forceinline__ void nn_capped(const GridDesc &g, float qx, float qy, float qz,
-                                          float &best, int &bpos, int &bidx, float *second = nullptr)
+// Walks four runs of candidates as one flat list, CH at a time.  `fetch(j)` returns point j
+// {x, y, z, original index} from wherever the caller keeps it (global memory, LDS).
+template <int CH, bool SECOND, class Fetch>
+__device__ __forceinline__ void scan_runs(const uint2 (&run)[4], float qx, float qy, float qz,
+                                          Fetch &&fetch, float &best, int &bpos, int &bidx,
+                                          float *second)
 {
-    best = INFINITY; bpos = -1; bidx = 0x7fffffff;
-    if (SECOND) *second = INFINITY;
-    int cx, cy, cz;
-    if (!probe_origin(g, qx, qy, qz, cx, cy, cz)) return;
-
-    int rank[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        rank[r] = g.dir[dir_index(g, cx, cy + (r & 1), cz + (r >> 1))];
-    uint2 run[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        // an unranked block has no entry: read entry 0 of the table and drop it
-        int e = rank[r] >= 0 ? rank[r] * 64 + cell_local(cx, cy + (r & 1), cz + (r >> 1)) : 0;
-        uint2 v = g.run2[e];
-        run[r] = rank[r] >= 0 ? v : make_uint2(0u, 0u);
-    }
     constexpr int C = CH;
     static_assert(C >= 2 && C % 2 == 0, "candidates are evaluated in pairs");
     const unsigned P1 = run[0].y - run[0].x;
@@ -147,7 +126,7 @@ __device__ __forceinline__ void nn_capped(const GridDesc &g, float qx, float qy,
             unsigned ff = f + c;
             unsigned j = ff + (ff < P1 ? o0 : ff < P2 ? o1 : ff < P3 ? o2 : o3);
             jj[c] = ff < T ? j : 0u;     // past the end: re-read point 0, result dropped
-            p[c] = g.pts[jj[c]];
+            p[c] = fetch(jj[c]);
         }
 #pragma unroll
         for (int c = 0; c < C; c += 2) {
@@ -179,6 +158,38 @@ __device__ __forceinline__ void nn_capped(const GridDesc &g, float qx, float qy,
         bidx = (int)(unsigned)bkey;
     }
     if (SECOND) *second = b2;
+}
+
+// Nearest target point within the probe radius: the 1-NN the ICP loop needs.
+// best = +inf, bpos = -1 when the probed cells are empty.
+//
+// The four runs are walked as one flat candidate list, CH candidates at a
+// time: the CH loads of a chunk are issued together (one memory latency per
+// chunk instead of one per candidate) and a wave iterates max-over-lanes of
+// the TOTAL candidate count, not the sum of per-run maxima.
+template <int CH, bool SECOND = false>
+__device__ __forceinline__ void nn_capped(const GridDesc &g, float qx, float qy, float qz,
+                                          float &best, int &bpos, int &bidx, float *second = nullptr)
+{
+    best = INFINITY; bpos = -1; bidx = 0x7fffffff;
+    if (SECOND) *second = INFINITY;
+    int cx, cy, cz;
+    if (!probe_origin(g, qx, qy, qz, cx, cy, cz)) return;
+
+    int rank[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        rank[r] = g.dir[dir_index(g, cx, cy + (r & 1), cz + (r >> 1))];
+    uint2 run[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // an unranked block has no entry: read entry 0 of the table and drop it
+        int e = rank[r] >= 0 ? rank[r] * 64 + cell_local(cx, cy + (r & 1), cz + (r >> 1)) : 0;
+        uint2 v = g.run2[e];
+        run[r] = rank[r] >= 0 ? v : make_uint2(0u, 0u);
+    }
+    scan_runs<CH, SECOND>(run, qx, qy, qz, [&](unsigned j) { return g.pts[j]; }, best, bpos, bidx,
+                          second);
 }
 
 // Visits every target point in the cell box [x0,x1] x [y0,y1] x [z0,z1]
