@@ -126,8 +126,8 @@ def test_knn_class(pair, po):
 
 
 def test_cpp_driver_runs_like_test_cpp(pair, tmp_path):
-    """examples/test.cpp is the reference's test.cpp with only the include lines
-    changed; it must print the golden transform (test.cpp:14-29)."""
+    """examples/register_pair.cpp makes the calls of the reference's driver (test.cpp:16-24)
+    through the drop-in classes; it must print the golden transform."""
     import os
     import subprocess
     ref, src, gold = pair
