@@ -301,6 +301,16 @@ void orc_eig3_smallest(const double Win[9], double v_out[3], double *eval_out)
 
 /* ------------------------------------------------------------------ */
 /* CPoint2PlaneICP::calcNormals (CPoint2PlaneICP.cpp:122-154)          */
+/* The reference hard-codes these two numbers; the library exposes them as options,
+ * so the checker can be told the same values (defaults: the reference's). */
+static float g_dist_threshold = 5.0f;   /* CPoint2PlaneICP.cpp:68  */
+static int g_normals_k = 20;            /* CPoint2PlaneICP.cpp:125 */
+void orc_set_constants(float dist_threshold, int normals_k)
+{
+    g_dist_threshold = dist_threshold;
+    g_normals_k = normals_k;
+}
+
 /* 20-NN of each reference point including itself; raw second moments  */
 /* about the origin, each term fl32(fl32(pj*pi)/20) summed in fp64;    */
 /* eigenvector of the smallest eigenvalue stored as fp32.              */
@@ -308,7 +318,7 @@ void orc_eig3_smallest(const double Win[9], double v_out[3], double *eval_out)
 void orc_calc_normals(const orc_kdtree *T, const float *ref, int64_t m, float *normals,
                       int32_t *knn_idx_out /* m*20 or NULL */, int threads)
 {
-    const int K = 20;
+    const int K = g_normals_k;                                       /* 20 at :125 */
     int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)m * K);
     float *d2 = (float *)malloc(sizeof(float) * (size_t)m * K);
     orc_kdtree_knn(T, ref, m, K, idx, d2, threads);
@@ -321,7 +331,7 @@ void orc_calc_normals(const orc_kdtree *T, const float *ref, int64_t m, float *n
                 for (int i = 0; i < 3; ++i) {
                     float pw = 1.0f;                                  /* pWeight[k] :135 */
                     float prod = ref[3 * id + j] * ref[3 * id + i];   /* float * float   */
-                    float term = pw * prod / 20;                      /* :144, all fp32  */
+                    float term = pw * prod / K;                       /* :144, all fp32  */
                     W[3 * j + i] += (double)term;
                 }
         }
@@ -385,7 +395,7 @@ static int single_run(const orc_kdtree *T, const float *ref, const float *normal
 {
     orc_kdtree_knn(T, move, n, 1, idx, d2, threads);           /* :65-67 */
 
-    const float distthreshold = 5.0f;                          /* :68 */
+    const float distthreshold = g_dist_threshold;              /* 5.0f at :68 */
     float *weight = (float *)calloc((size_t)(n > 0 ? n : 1), sizeof(float));
     for (int64_t i = 0; i < n; ++i) {                          /* :70-79 */
         if (d2[i] <= distthreshold) {

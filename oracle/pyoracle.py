@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_NORMALS_K = 20
 
 
 def build(force=False):
@@ -114,7 +115,7 @@ def eig3_smallest(W):
 def calc_normals(tree, threads=1, want_knn=False):
     m = tree.ref.shape[0]
     normals = np.empty((m, 3), np.float32)
-    knn = np.empty((m, 20), np.int32) if want_knn else None
+    knn = np.empty((m, _NORMALS_K), np.int32) if want_knn else None
     lib().orc_calc_normals(
         tree._h, _f(tree.ref), m, _f(normals), _i(knn) if want_knn else None, threads
     )
@@ -138,6 +139,15 @@ def icp_point2plane(tree, normals, src, iters, faithful=True, threads=1, history
         1 if faithful else 0, threads,
     )
     return dict(rc=rc, trans=trans.reshape(4, 4), X=X, info=info, idx=idx, d2=d2, src=src)
+
+
+def set_constants(dist_threshold=5.0, normals_k=20):
+    """The two numbers the reference hard-codes (CPoint2PlaneICP.cpp:68, :125)."""
+    L = lib()
+    L.orc_set_constants.argtypes = [C.c_float, C.c_int]
+    L.orc_set_constants(float(dist_threshold), int(normals_k))
+    global _NORMALS_K
+    _NORMALS_K = int(normals_k)
 
 
 def parse_txt(text: bytes):

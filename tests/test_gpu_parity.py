@@ -461,3 +461,29 @@ def test_search_counts_fall_as_the_registration_settles(ctx):
     ctx.run(4)
     assert np.all(ctx.search_counts() == len(src))
     ctx.set_options(coherent=1)
+
+
+@pytest.mark.parametrize("thr,k", [(2.0, 20), (12.5, 8), (5.0, 33)])
+def test_options_other_than_the_reference_constants(po, pair, thr, k):
+    """dist_threshold and normals_k are options of the library (the reference hard-codes 5 and
+    20, CPoint2PlaneICP.cpp:68, :125); the oracle is told the same numbers."""
+    import stereovision_amd as sv
+    ref, src, _ = pair
+    po.set_constants(thr, k)
+    try:
+        tree = po.KDTree(ref)
+        normals = po.calc_normals(tree)
+        want = po.icp_point2plane(tree, normals, src, 6)
+    finally:
+        po.set_constants()
+    c = sv.Context(0, dist_threshold=thr, normals_k=k)
+    c.set_target(ref)
+    c.set_source(src)
+    T, info = c.run(6)
+    X, I = c.history()
+    got_n = c.get_normals()
+    flip = np.sign((got_n * normals).sum(1))
+    assert np.abs(got_n * flip[:, None] - normals).max() < 2e-6
+    assert np.array_equal(I[:, 0], want["info"][:, 0])
+    assert np.abs(X - want["X"]).max() < 1e-7
+    _check_transform(T, want["trans"], _extent(ref))
