@@ -35,4 +35,28 @@ public:
         for (size_t i = 0; i < values.size(); ++i) buf[i] = values[i];
         return flann::Matrix<float>(buf, rows, 3);
     }
+
+    // Addition (no counterpart in the reference): the same cloud as raw little-endian
+    // float32 x y z triples, for clouds of many millions of points where parsing text takes
+    // longer than registering.  Same ownership rule as read().
+    flann::Matrix<float> readBinary(std::string path)
+    {
+        std::ifstream f(path, std::ios::binary | std::ios::ate);
+        flann::Matrix<float> data;
+        if (!f.is_open()) return data;
+        const std::streamoff bytes = f.tellg();
+        const size_t rows = (size_t)bytes / (3 * sizeof(float));
+        float *buf = new float[rows ? rows * 3 : 1];
+        f.seekg(0);
+        f.read(reinterpret_cast<char *>(buf), (std::streamsize)(rows * 3 * sizeof(float)));
+        return flann::Matrix<float>(buf, rows, 3);
+    }
+
+    static bool writeBinary(std::string path, flann::Matrix<float> cloud)
+    {
+        std::ofstream f(path, std::ios::binary);
+        if (!f.is_open()) return false;
+        f.write(reinterpret_cast<const char *>(cloud.ptr()), (std::streamsize)(cloud.rows * 3 * sizeof(float)));
+        return (bool)f;
+    }
 };

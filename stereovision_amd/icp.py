@@ -373,6 +373,19 @@ class CTxtReader:
         return np.asarray(vals[: rows * 3], dtype=np.float64).astype(np.float32).reshape(rows, 3)
 
 
+    # additions (no counterpart in the reference): raw little-endian float32 x y z triples
+    def readBinary(self, path):
+        try:
+            raw = np.fromfile(path, dtype="<f4")
+        except OSError:
+            return np.empty((0, 3), np.float32)
+        return np.ascontiguousarray(raw[: (raw.size // 3) * 3].reshape(-1, 3))
+
+    @staticmethod
+    def writeBinary(path, cloud):
+        np.ascontiguousarray(cloud, dtype="<f4").tofile(path)
+
+
 def _atof(tok):
     """C atof: the longest numeric prefix, 0.0 when there is none."""
     try:

@@ -18,6 +18,14 @@ def test_parse_matches_loadtxt(po, tmp_path):
     p.write_bytes(text)
     assert np.array_equal(CTxtReader().read(str(p)), got)
     assert CTxtReader().read(str(tmp_path / "missing.txt")).shape == (0, 3)
+    # the binary form round-trips the same cloud (and drops a trailing partial triple)
+    b = tmp_path / "c.bin"
+    CTxtReader.writeBinary(str(b), got)
+    assert np.array_equal(CTxtReader().readBinary(str(b)), got)
+    with open(b, "ab") as fh:
+        fh.write(np.float32([1.0]).tobytes())
+    assert np.array_equal(CTxtReader().readBinary(str(b)), got)
+    assert CTxtReader().readBinary(str(tmp_path / "missing.bin")).shape == (0, 3)
 
 
 def test_kdtree_equals_brute_random(po):
