@@ -39,6 +39,8 @@ def parse():
                     help="iterations of the CPU baseline sample; 0 disables it")
     ap.add_argument("--batch-pairs", type=int, default=64,
                     help="pairs (256^2 points each) per rank of the batched leg; 0 disables it")
+    ap.add_argument("--extras", type=int, default=1,
+                    help="1: also time normal estimation, point-to-point ICP and rectification maps")
     ap.add_argument("--cal-views", type=int, default=2000,
                     help="views of the calibration leg (11 x 8 board each); 0 disables the leg")
     return ap.parse_args()
@@ -285,6 +287,72 @@ def main():
                           f"{4 * V * cl.shape[1]} x {18 + 6 * V + 6} doubles cannot be allocated)",
             }
 
+    # ---- the rows next to the hot path, rank 0 only, small and bounded: normal estimation,
+    # the point-to-point variant, the rectification maps; each with the CPU checker beside it
+    neighbours = None
+    if rank == 0 and args.extras:
+        neighbours = {}
+        ectx = sv.Context(local)
+        ectx.set_target(tgt, None)                              # allocations
+        t0 = time.perf_counter()
+        ectx.set_target(tgt, None)                              # grid + 20-NN + eigenvectors
+        t_est = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ectx.set_target(tgt, nrm)
+        t_given = time.perf_counter() - t0
+        neighbours["normal_estimation"] = {
+            "workload": f"calcNormals on {len(tgt)} target points (20-NN, uncentred moments, "
+                        "smallest eigenvector), host call including the upload",
+            "ms": (t_est - t_given) * 1e3, "set_target_with_given_normals_ms": t_given * 1e3}
+        ectx.close()
+        pctx = sv.Context(local, dist_threshold=15.0)
+        pctx.set_target(tgt, tgt)
+        pctx.set_source(src)
+        pctx.run_point2point(args.iters)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            Tp, _ = pctx.run_point2point(args.iters)
+        dtp = (time.perf_counter() - t0) / 5
+        neighbours["point_to_point"] = {
+            "workload": f"CPoint2PointICP, same {n}-point pair, threshold 15, {args.iters} iterations",
+            "iters_per_s": args.iters / dtp}
+        pctx.close()
+        from stereovision_amd.calib import rectify_maps, stereo_rectify
+        KL = np.array([[1400.0, 0, 960.0], [0, 1400.0, 540.0], [0, 0, 1]])
+        KR = np.array([[1395.0, 0, 955.0], [0, 1398.0, 545.0], [0, 0, 1]])
+        dL = np.array([-0.28, 0.09, 1e-3, -5e-4, 0.01])
+        dR = np.array([-0.27, 0.08, -7e-4, 4e-4, -0.02])
+        cr, sr = np.cos(0.01), np.sin(0.01)
+        Rrig = np.array([[cr, 0, sr], [0, 1, 0], [-sr, 0, cr]])
+        pl, pr, _ = stereo_rectify(KL, KR, Rrig, [-90.0, 1.0, 2.0])
+        rectify_maps(1920, 1080, KL, dL, KR, dR, pl, pr, device=local)
+        *_, rect_ms = rectify_maps(1920, 1080, KL, dL, KR, dR, pl, pr, device=local, return_ms=True)
+        neighbours["rectify_maps"] = {
+            "workload": "doImageRectify, 1920 x 1080, both cameras, five distortion terms",
+            "kernel_ms": rect_ms, "GBs": 1920 * 1080 * 32 / (rect_ms * 1e-3) / 1e9}
+        if world == 1 and args.cpu_iters > 0:
+            from oracle import pyoracle as po
+            sub = 1 << 17                                       # a bounded sample for the CPU
+            t0 = time.perf_counter()
+            po.calc_normals(po.KDTree(tgt[:sub]), threads=1)
+            neighbours["normal_estimation"]["cpu_baseline"] = {
+                "value": sub / (time.perf_counter() - t0), "unit": "points/s", "cores": 1, "kind": "port",
+                "sample": f"first {sub} target points (tree build included)",
+                "gpu_points_per_s": len(tgt) / max(t_est - t_given, 1e-9)}
+            ptree = po.KDTree(tgt)
+            t0 = time.perf_counter()
+            rp = po.icp_point2point(ptree, src, 5, faithful=True, threads=1, history=False)
+            neighbours["point_to_point"]["cpu_baseline"] = {
+                "value": 5 / (time.perf_counter() - t0), "unit": "iters/s", "cores": 1, "kind": "port",
+                "sample": "5 iterations of the same pair, tree build excluded"}
+            t0 = time.perf_counter()
+            po.rectify_maps(1920, 1080, KL, dL, KR, dR, pl, pr)
+            neighbours["rectify_maps"]["cpu_baseline"] = {
+                "value": (time.perf_counter() - t0) * 1e3, "unit": "ms", "cores": 1, "kind": "port",
+                "sample": "the same 1920 x 1080 maps (the inverse projection formed once, not per "
+                          "pixel as the reference does)"}
+
     # ---- CPU baseline: the oracle on the same pair, one thread ------------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_iters > 0:
@@ -367,6 +435,7 @@ def main():
             "sharded": sharded,
             "batched": batched,
             "calibration": calibration,
+            "neighbouring_rows": neighbours,
         }
         print(json.dumps(out))
     ctx.close()
