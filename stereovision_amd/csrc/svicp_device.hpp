@@ -25,6 +25,15 @@ constexpr int kNumSums = 32;   // 21 JtJ + 6 Jtr + inliers + sum w b^2 + sum w +
 // and the solve adds the copies up in a fixed order.
 constexpr int kDeltaCopies = 4;   // measured: 1 copy costs 9 us per search-heavy iteration, 16 slow the solve
 constexpr int kDeltaRow = kDeltaCopies * kNumSums;   // doubles per iteration
+// Relative slack of the proof that a remembered correspondence still holds.  A computed
+// fp32 squared distance is within 5 * 2^-24 = 3e-7 of the true one and a computed square root
+// within 2^-24: every bound is relaxed by kSlack on the distance (three times that on a
+// squared distance), several times what rounding can add up to.
+#ifndef SVICP_SLACK
+#define SVICP_SLACK 1e-6f
+#endif
+constexpr float kSlackUp = 1.0f + SVICP_SLACK, kSlackDown = 1.0f - SVICP_SLACK,
+                kSlackUp2 = 1.0f + 3.0f * SVICP_SLACK;
 constexpr int kMaxRing = 8;    // exact search: rings tried before the brute-force pass
 constexpr int kKnnMaxRing = 8; // the same for the k-NN facade
 
@@ -713,7 +722,7 @@ __device__ __forceinline__ void iterate_tile(
             for (int sl = 0; sl < NP; ++sl) {
                 const long long i = tile0 + sl * kItThreads + (int)threadIdx.x;
                 float lbn = lb[sl];
-                if (m2[sl] > 0.f) lbn = (lbn - sqrtf(m2[sl]) * 1.00001f) * 0.99999f;
+                if (m2[sl] > 0.f) lbn = (lbn - sqrtf(m2[sl]) * kSlackUp) * kSlackDown;
                 const int pos = __float_as_int(tp[sl].w);
                 float dx = px[sl] - tp[sl].x, dy = py[sl] - tp[sl].y, dz = pz[sl] - tp[sl].z;
                 float d2 = __fmul_rn(dx, dx);
@@ -724,7 +733,7 @@ __device__ __forceinline__ void iterate_tile(
                 // at this very position established, near-ties included
                 const bool still = m2[sl] == 0.f;
                 const bool proven_nn =
-                    pos >= 0 && (still || (lbn > 0.f && d2 * 1.00003f < lbn * lbn));
+                    pos >= 0 && (still || (lbn > 0.f && d2 * kSlackUp2 < lbn * lbn));
                 const bool proven_none = pos < 0 && (still || lbn > cp.root_hi);
                 need_search[sl] = live[sl] && !(proven_nn || proven_none);
                 if (live[sl] && !need_search[sl] && m2[sl] > 0.f) ps.lb[i] = lbn;
@@ -776,14 +785,16 @@ __device__ __forceinline__ void iterate_tile(
         nn_capped<CH, true>(g, e.x, e.y, e.z, best, bpos, bidx, &second);
         float4 tp = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
-        float lbn = cp.cov * 0.99999f;
-        if (bpos >= 0 && sqrtf(best) * 1.00001f <= cp.cov) {
+        // a point without an accepted neighbour has every target farther than cov / kSlackUp
+        // (computed), hence farther than cov * kSlackDown^2 in truth
+        float lbn = cp.cov * kSlackDown * kSlackDown;
+        if (bpos >= 0 && sqrtf(best) * kSlackUp <= cp.cov) {
             // no unprobed point can be nearer: bpos is the nearest neighbour
             float4 t = g.pts[bpos];
             const size_t o = 3 * (size_t)bpos;
             tp = make_float4(t.x, t.y, t.z, __int_as_float(bpos));
             nv = make_float4(g.nrm[o], g.nrm[o + 1], g.nrm[o + 2], 0.f);
-            lbn = fminf(sqrtf(second) * 0.99999f, lbn);
+            lbn = fminf(sqrtf(second) * kSlackDown, lbn);
             if (best <= cp.thr)
                 accumulate_point(acc, e.x, e.y, e.z, best, cp.thr, t.x, t.y, t.z, nv.x, nv.y, nv.z);
         }
