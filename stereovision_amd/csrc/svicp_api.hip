@@ -71,6 +71,7 @@ struct svicp_ctx {
     int cur = 0;   // 0: the pristine copy is current, 1: the work copy
     DevBuf sx0, sy0, sz0, wx, wy, wz, perm;
     DevBuf st_tp, st_nv, st_lb;   // per source point: matched target point, normal, bound
+    DevBuf tile_flags;            // [2][kFlagCap] bytes: which tiles had work in the last two iterations
 
     // scratch shared by the set-up steps
     DevBuf tmp_aos, keys_a, keys_b, vals_a, vals_b, marks, ranks, block_of_rank, sort_tmp, bbox6;
@@ -264,6 +265,10 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
         }
     }
     HIPCHK(ctx->partials.reserve(sizeof(double) * kNumSums * nb));
+    if (!ctx->tile_flags.p) {
+        HIPCHK(ctx->tile_flags.reserve(2 * kFlagCap));
+        HIPCHK(hipMemsetAsync(ctx->tile_flags.p, 0, 2 * kFlagCap, ctx->stream));
+    }
     HIPCHK(ctx->state.reserve(sizeof(IcpState)));
     if (iters > ctx->hist_cap) {
         drop_graph(ctx);
@@ -297,6 +302,7 @@ void launch_iteration(svicp_ctx *ctx, int k, double *partials)
     ps.tp = ctx->st_tp.as<float4>();
     ps.nv = ctx->st_nv.as<float4>();
     ps.lb = ctx->st_lb.as<float>();
+    ps.active = ctx->nb <= kFlagCap ? ctx->tile_flags.as<unsigned char>() : nullptr;
     float *wx = ctx->wx.as<float>(), *wy = ctx->wy.as<float>(), *wz = ctx->wz.as<float>();
     const float *x0 = ctx->sx0.as<float>(), *y0 = ctx->sy0.as<float>(), *z0 = ctx->sz0.as<float>();
     IcpState *state = ctx->state.as<IcpState>();
@@ -418,7 +424,7 @@ int svicp_destroy(svicp_ctx *ctx)
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     DevBuf *bufs[] = { &ctx->tgt_aos, &ctx->nrm_aos, &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->run2,
                        &ctx->end1, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx, &ctx->wy, &ctx->wz,
-                       &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->perm, &ctx->tmp_aos, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
+                       &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->tile_flags, &ctx->perm, &ctx->tmp_aos, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
                        &ctx->vals_b, &ctx->marks, &ctx->ranks, &ctx->block_of_rank,
                        &ctx->sort_tmp, &ctx->bbox6, &ctx->knn_idx, &ctx->knn_d2,
                        &ctx->unresolved, &ctx->n_unres, &ctx->partials, &ctx->totals, &ctx->deltas, &ctx->state, &ctx->xhist,
@@ -944,6 +950,23 @@ int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info)
     return SVICP_OK;
 }
 
+#ifdef SVICP_TRACE
+// development builds only: the phase stamps of the last run (see SVICP_STAMP)
+int svicp_debug_trace(unsigned long long *out, size_t count)
+{
+    const size_t all = (size_t)kTraceIters * kTraceTiles * kTraceStamps;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * std::min(count, all))
+               == hipSuccess ? 0 : SVICP_ERR_HIP;
+}
+int svicp_debug_trace_clear(void)
+{
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace)) != hipSuccess) return SVICP_ERR_HIP;
+    return hipMemset(p, 0, sizeof(unsigned long long) * kTraceIters * kTraceTiles * kTraceStamps)
+               == hipSuccess ? 0 : SVICP_ERR_HIP;
+}
+#endif
+
 int svicp_kernel_times(svicp_ctx *ctx, double *fused_ms, double *solve_ms, int *launches)
 {
     if (!ctx) return SVICP_ERR_ARG;
@@ -1155,6 +1178,7 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
         P.cp.root_hi = std::sqrt(thr) * 1.00001f;
         P.cp.cov = std::sqrt(thr) * 1.001f;
         P.ps.tp = c->st_tp.as<float4>(); P.ps.nv = c->st_nv.as<float4>(); P.ps.lb = c->st_lb.as<float>();
+        P.ps.active = nullptr;   // the batch has its own block table
         P.partials = c->partials.as<double>();
         for (int t = 0; t < c->nb; ++t) map.push_back(make_int2(i, t));
     }

@@ -18,6 +18,25 @@
 
 namespace svicp {
 
+// Development builds (-DSVICP_TRACE) stamp the phases of every block of the iteration
+// kernel with the 100 MHz wall clock; svicp_debug_trace() copies the stamps out.
+#ifdef SVICP_TRACE
+constexpr int kTraceIters = 64, kTraceTiles = 1024, kTraceStamps = 16;
+__device__ unsigned long long g_trace[kTraceIters * kTraceTiles * kTraceStamps];
+#define SVICP_STAMP(k)                                                                    \
+    do {                                                                                  \
+        if (threadIdx.x == 0 && iter < kTraceIters && tile < kTraceTiles)                 \
+            g_trace[((size_t)iter * kTraceTiles + tile) * kTraceStamps + (k)] = wall_clock64(); \
+    } while (0)
+#define SVICP_SOLVE_STAMP(k)                                                              \
+    do {                                                                                  \
+        if (t == 0 && trace_row) trace_row[k] = wall_clock64();                            \
+    } while (0)
+#else
+#define SVICP_STAMP(k) do { } while (0)
+#define SVICP_SOLVE_STAMP(k) do { } while (0)
+#endif
+
 constexpr int kBlockThreads = 256;
 constexpr int kNumSums = 32;   // 21 JtJ + 6 Jtr + inliers + sum w b^2 + sum w + 2 pad
 // Same-address fp64 atomics serialise in L2 (about 6 ns each): the per-iteration change of
@@ -201,6 +220,74 @@ __device__ __forceinline__ void nn_capped(const GridDesc &g, float qx, float qy,
                           second);
 }
 
+// The same search by one whole wave for ONE query (all lanes pass the same q): the four
+// table look-ups run on four lanes, the candidates are spread over the lanes, and a
+// butterfly picks the winner.  Same candidates, same distance arithmetic and the same
+// order rule as nn_capped, so the same answer; the chain of dependent loads is table,
+// run, candidates instead of one load per chunk of candidates.  `bpt` is the winning
+// target point.  Results are uniform over the wave.
+template <bool SECOND>
+__device__ __forceinline__ void nn_capped_wave(const GridDesc &g, float qx, float qy, float qz,
+                                               float &best, int &bpos, int &bidx, float4 &bpt,
+                                               float *second)
+{
+    best = INFINITY; bpos = -1; bidx = 0x7fffffff;
+    bpt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SECOND) *second = INFINITY;
+    int cx, cy, cz;
+    if (!probe_origin(g, qx, qy, qz, cx, cy, cz)) return;
+    const int lane = threadIdx.x & 63, r = lane & 3;
+    const int rank = g.dir[dir_index(g, cx, cy + (r & 1), cz + (r >> 1))];
+    const int e = rank >= 0 ? rank * 64 + cell_local(cx, cy + (r & 1), cz + (r >> 1)) : 0;
+    uint2 mine = g.run2[e];
+    if (rank < 0) mine = make_uint2(0u, 0u);
+    uint2 run[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        run[k].x = (unsigned)__builtin_amdgcn_readlane((int)mine.x, k);
+        run[k].y = (unsigned)__builtin_amdgcn_readlane((int)mine.y, k);
+    }
+    const unsigned P1 = run[0].y - run[0].x;
+    const unsigned P2 = P1 + (run[1].y - run[1].x);
+    const unsigned P3 = P2 + (run[2].y - run[2].x);
+    const unsigned T = P3 + (run[3].y - run[3].x);
+    const unsigned o0 = run[0].x, o1 = run[1].x - P1, o2 = run[2].x - P2, o3 = run[3].x - P3;
+    unsigned long long bkey = (unsigned long long)0x7f800000u << 32;
+    float b1 = INFINITY, b2 = INFINITY;
+    float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
+    int mpos = -1;
+    for (unsigned f = lane; f < T; f += 64) {
+        const unsigned j = f + (f < P1 ? o0 : f < P2 ? o1 : f < P3 ? o2 : o3);
+        const float4 p = g.pts[j];
+        const float d = dist2(qx, qy, qz, p);
+        const unsigned long long key =
+            ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(p.w);
+        if (key < bkey) { bkey = key; mp = p; mpos = (int)j; }
+        b2 = fminf(b2, fmaxf(d, b1));
+        b1 = fminf(b1, d);
+    }
+    unsigned long long wkey = bkey;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(wkey, off, 64);
+        wkey = o < wkey ? o : wkey;
+        if (SECOND) {
+            const float c1 = __shfl_xor(b1, off, 64), c2 = __shfl_xor(b2, off, 64);
+            b2 = fminf(fmaxf(b1, c1), fminf(b2, c2));
+            b1 = fminf(b1, c1);
+        }
+    }
+    const unsigned long long owners = __ballot(mpos >= 0 && bkey == wkey);
+    if (owners == 0ull) return;                       // no candidate at all
+    const int w = __ffsll((long long)owners) - 1;     // keys are distinct: one owner
+    bpos = __shfl(mpos, w, 64);
+    bpt.x = __shfl(mp.x, w, 64); bpt.y = __shfl(mp.y, w, 64); bpt.z = __shfl(mp.z, w, 64);
+    bpt.w = __shfl(mp.w, w, 64);
+    best = __uint_as_float((unsigned)(wkey >> 32));
+    bidx = (int)(unsigned)wkey;
+    if (SECOND) *second = b2;
+}
+
 // Visits every target point in the cell box [x0,x1] x [y0,y1] x [z0,z1]
 // (already clipped to the grid) exactly once.
 template <class F>
@@ -317,14 +404,16 @@ __device__ __forceinline__ void accumulate_point(double (&acc)[30], float px, fl
     double wd = (double)w, bd = (double)b;
     int v = 0;
 #pragma unroll
+    // the sums are fp64 and their order is free (the reference adds them in point order);
+    // fused multiply-adds halve the fp64 work of this step
     for (int r = 0; r < 6; ++r) {
         double aw = a[r] * wd;
 #pragma unroll
-        for (int c = r; c < 6; ++c) acc[v++] += aw * a[c];
-        acc[21 + r] += aw * bd;
+        for (int c = r; c < 6; ++c) { acc[v] = fma(aw, a[c], acc[v]); ++v; }
+        acc[21 + r] = fma(aw, bd, acc[21 + r]);
     }
     if (w > 0.f) acc[27] += 1.0;
-    acc[28] += wd * bd * bd;
+    acc[28] = fma(wd * bd, bd, acc[28]);
     acc[29] += wd;
 }
 
@@ -397,20 +486,60 @@ struct PointState {
     float4 *tp;       // {tx, ty, tz, pos as int bits}
     float4 *nv;       // {nx, ny, nz, unused}
     float *lb;
+    // [2][kFlagCap] bytes or null: bit 0 of byte t of row (k & 1) says whether tile t had
+    // work to do in iteration k (see choose_tile)
+    unsigned char *active;
 };
+constexpr int kFlagCap = 1024;   // tiles the adaptive block order handles (16 per lane of a wave)
 
 // ------------------------------------------------------------------------
 // 6x6 solve and transform update on the device.
 // Restates CPoint2PlaneICP.cpp:109 (X), :111-119 (R = Rz*Ry*Rx, T) and
 // :36-39 / :52-55 (Trans = [R T; 0 1] * Trans).
 // ------------------------------------------------------------------------
-// 1/sqrt(a) to fp64 accuracy: fp32 estimate, three Newton steps.
+// 1/sqrt(a) to fp64 accuracy: the hardware estimate (about 2^-23 relative) and two Newton
+// steps, each y <- y + (y/2) * (1 - a*y*y): 1e-7 -> 2e-14 -> rounding level.
 __device__ __forceinline__ double fast_rsqrt(double a)
 {
-    double y = (double)rsqrtf((float)a);
+    double y = __builtin_amdgcn_rsq(a);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) y = y * (1.5 - 0.5 * a * y * y);
+    for (int k = 0; k < 2; ++k) {
+        const double e = fma(-(a * y), y, 1.0);
+        y = fma(0.5 * y, e, y);
+    }
     return y;
+}
+
+// 2^-floor(e/2) for a = f * 2^e, 1 <= f < 2: a power of two near 1/sqrt(a).  Scaling rows
+// and columns by it is exact and leaves the diagonal in [1, 4).
+__device__ __forceinline__ double pow2_rsqrt(double a)
+{
+    const int e = (int)((__double_as_longlong(a) >> 52) & 0x7ff) - 1023;
+    return __longlong_as_double((long long)(1023 - (e >> 1)) << 52);
+}
+
+// sin and cos of a small angle by their Taylor polynomials (|x| <= 0.5: the first
+// neglected terms are 0.5^17/17! and 0.5^18/18!, far below one rounding).
+__device__ __forceinline__ void sincos_small(double x, double &sn, double &cs)
+{
+    const double z = x * x;
+    double s = -1.0 / 1307674368000.0;          // -1/15!
+    s = fma(s, z, 1.0 / 6227020800.0);          //  1/13!
+    s = fma(s, z, -1.0 / 39916800.0);           // -1/11!
+    s = fma(s, z, 1.0 / 362880.0);              //  1/9!
+    s = fma(s, z, -1.0 / 5040.0);               // -1/7!
+    s = fma(s, z, 1.0 / 120.0);                 //  1/5!
+    s = fma(s, z, -1.0 / 6.0);                  // -1/3!
+    sn = fma(x * z, s, x);
+    double c = 1.0 / 20922789888000.0;          //  1/16!
+    c = fma(c, z, -1.0 / 87178291200.0);        // -1/14!
+    c = fma(c, z, 1.0 / 479001600.0);           //  1/12!
+    c = fma(c, z, -1.0 / 3628800.0);            // -1/10!
+    c = fma(c, z, 1.0 / 40320.0);               //  1/8!
+    c = fma(c, z, -1.0 / 720.0);                // -1/6!
+    c = fma(c, z, 1.0 / 24.0);                  //  1/4!
+    c = fma(c, z, -0.5);
+    cs = fma(c, z, 1.0);
 }
 
 // Orders LDS writes before later LDS reads of the same wave (no s_barrier:
@@ -441,9 +570,32 @@ __device__ __forceinline__ double lane_bcast(double v, int lane)
 // factorisation.  Lanes >= 7 run the same instructions on values nobody reads.
 // Restates CPoint2PlaneICP.cpp:109 (X), :111-119 (R = Rz*Ry*Rx, T) and
 // :36-39 / :52-55 (Trans = [R T; 0 1] * Trans).
-__device__ inline void solve_and_update(const double *base, const double *delta, double *totals,
+// The loads behind the running totals, issued by request_sums() and consumed by
+// solve_and_update().  Vector loads return in issue order, so the wave that solves asks
+// for these before anything else it loads.
+struct SumsInFlight {
+    double base, delta[kDeltaCopies];
+};
+
+__device__ __forceinline__ SumsInFlight request_sums(const double *base, const double *delta)
+{
+    const int t = threadIdx.x & 63;
+    SumsInFlight s;
+    s.base = 0.0;
+#pragma unroll
+    for (int cp = 0; cp < kDeltaCopies; ++cp) s.delta[cp] = 0.0;
+    if (t < 30) {
+        s.base = base[t];
+#pragma unroll
+        for (int cp = 0; cp < kDeltaCopies; ++cp) s.delta[cp] = delta[cp * kNumSums + t];
+    }
+    return s;
+}
+
+__device__ inline void solve_and_update(const SumsInFlight &sums, double *totals,
                                         IcpState *st, double *X_hist, double *info_hist,
-                                        int iter, bool record, double *out_rt)
+                                        int iter, bool record, double *out_rt,
+                                        unsigned long long *trace_row = nullptr)
 {
     const int t = threadIdx.x & 63;
     const int row = t < 7 ? t : 6;
@@ -456,10 +608,11 @@ __device__ inline void solve_and_update(const double *base, const double *delta,
     if (t < 30) {
         double dsum = 0.0;
 #pragma unroll
-        for (int cp = 0; cp < kDeltaCopies; ++cp) dsum += delta[cp * kNumSums + t];
-        stat = base[t] + dsum;
+        for (int cp = 0; cp < kDeltaCopies; ++cp) dsum += sums.delta[cp];
+        stat = sums.base + dsum;
     }
     if (record && t < kNumSums) totals[t] = stat;
+    SVICP_SOLVE_STAMP(10);
     double m[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -468,14 +621,14 @@ __device__ inline void solve_and_update(const double *base, const double *delta,
         m[c] = __shfl(stat, at, 64);
     }
 
-    // scaling d = diag^-1/2
+    // scaling d ~ diag^-1/2, a power of two (exact)
     double d[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         const double a = lane_bcast(m[c], c);
         const bool good = a > 1e-300 && a < 1e300;
         ok = ok && good;
-        d[c] = good ? fast_rsqrt(a) : 1.0;
+        d[c] = good ? pow2_rsqrt(a) : 1.0;
     }
     double dmine = 1.0;                     // the rhs row is scaled by the columns only
 #pragma unroll
@@ -483,6 +636,7 @@ __device__ inline void solve_and_update(const double *base, const double *delta,
 #pragma unroll
     for (int c = 0; c < 6; ++c) m[c] = m[c] * dmine * d[c];
 
+    SVICP_SOLVE_STAMP(11);
     double inv[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -491,19 +645,20 @@ __device__ inline void solve_and_update(const double *base, const double *delta,
         for (int k = 0; k < c; ++k) lc[k] = lane_bcast(m[k], c);
         double v = m[c];
 #pragma unroll
-        for (int k = 0; k < c; ++k) v -= m[k] * lc[k];
+        for (int k = 0; k < c; ++k) v = fma(-m[k], lc[k], v);
         double piv = lane_bcast(v, c);
         if (!(piv > 1e-14) || !(piv < 1e300)) { ok = false; piv = 1.0; }
         inv[c] = fast_rsqrt(piv);
         m[c] = v * inv[c];                  // lane c: sqrt(piv); lanes > c: L[r][c]; lane 6: y[c]
     }
+    SVICP_SOLVE_STAMP(12);
     // back substitution L^T x = y
     double x[6];
 #pragma unroll
     for (int r = 5; r >= 0; --r) {
         double v = lane_bcast(m[r], 6);
 #pragma unroll
-        for (int k = r + 1; k < 6; ++k) v -= lane_bcast(m[r], k) * x[k];
+        for (int k = r + 1; k < 6; ++k) v = fma(-lane_bcast(m[r], k), x[k], v);
         x[r] = v * inv[r];
     }
 #pragma unroll
@@ -515,9 +670,12 @@ __device__ inline void solve_and_update(const double *base, const double *delta,
 #pragma unroll
         for (int r = 0; r < 6; ++r) x[r] = 0.0;
     }
+    SVICP_SOLVE_STAMP(13);
     // the three angles' sines and cosines on three lanes at once
     double sn, cs;
-    sincos(t == 0 ? x[0] : t == 1 ? x[1] : x[2], &sn, &cs);
+    const double ang = t == 0 ? x[0] : t == 1 ? x[1] : x[2];
+    if (fabs(x[0]) <= 0.5 && fabs(x[1]) <= 0.5 && fabs(x[2]) <= 0.5) sincos_small(ang, sn, cs);
+    else sincos(ang, &sn, &cs);
     const double sx = lane_bcast(sn, 0), cx = lane_bcast(cs, 0), sy = lane_bcast(sn, 1),
                  cy = lane_bcast(cs, 1), sz = lane_bcast(sn, 2), cz = lane_bcast(cs, 2);
     // R = Rz(X2) * Ry(X1) * Rx(X0)
@@ -529,6 +687,7 @@ __device__ inline void solve_and_update(const double *base, const double *delta,
         for (int k = 0; k < 9; ++k) out_rt[k] = R[k];
         out_rt[9] = x[3]; out_rt[10] = x[4]; out_rt[11] = x[5];
     }
+    SVICP_SOLVE_STAMP(14);
     if (!record) return;
 
     // Trans = [R T; 0 1] * Trans, one element per lane
@@ -607,6 +766,76 @@ __device__ __forceinline__ int xcd_contiguous(int block, int nb)
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
 }
 
+// Inclusive prefix sum over the 64 lanes by data-parallel-primitive moves.
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ int dpp_get(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, BOUND);
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    v += dpp_get<0x111, 0xf, true>(v);    // row_shr:1 (0 from outside the row of 16)
+    v += dpp_get<0x112, 0xf, true>(v);    // row_shr:2
+    v += dpp_get<0x114, 0xf, true>(v);    // row_shr:4
+    v += dpp_get<0x118, 0xf, true>(v);    // row_shr:8   -> scan inside each row
+    v += dpp_get<0x142, 0xa, false>(v);   // row_bcast:15: rows 1 and 3 add the row before
+    v += dpp_get<0x143, 0xc, false>(v);   // row_bcast:31: rows 2 and 3 add rows 0 + 1
+    return v;
+}
+
+// Which tile block `b` takes in iteration `iter`, given which tiles had work in the
+// iteration before (`prev`, one byte per tile).  Once a registration has settled, few
+// tiles still have work (points that keep changing in their last fp32 bits) and they are
+// the same from one iteration to the next, but they come in runs with power-of-two
+// strides (they follow the coordinate planes through the Morton order), which a fixed
+// block order keeps stacking on the same compute units: the launch then ends with the
+// unit that got three of them.  The dispatcher places block b of a fresh launch by
+// b mod 256 (XCD b mod 8, compute unit (b / 8) mod 32), so here the tiles that had work
+// take the first blocks, one per compute unit while they are at most 256, neighbours on
+// one XCD, and the tiles without work take the rest.  With every tile active this is
+// xcd_contiguous itself.  Every wave of every block evaluates the same flags, so the
+// result is a permutation of the tiles.  `predicted`: the tile had work last time.
+// Position of the r-th (from 0) set bit of the 16-bit mask m; r < popcount(m).
+__device__ __forceinline__ int select16(unsigned m, int r)
+{
+    int pos = 0;
+    int c = __popc(m & 0xffu);
+    if (r >= c) { r -= c; pos += 8; m >>= 8; }
+    c = __popc(m & 0xfu);
+    if (r >= c) { r -= c; pos += 4; m >>= 4; }
+    c = __popc(m & 0x3u);
+    if (r >= c) { r -= c; pos += 2; m >>= 2; }
+    if (r >= (int)(m & 1u)) pos += 1;
+    return pos;
+}
+
+__device__ __forceinline__ int choose_tile(const uint4 v, int nb, int b, bool &predicted,
+                                           int &n_predicted)
+{
+    const int lane = threadIdx.x & 63;                             // v: the flag bytes of 16 tiles
+    // bit 0 of byte k of a word to bit k of a nibble: the products land on distinct bits
+    auto nib = [](unsigned w) { return (((w & 0x01010101u) * 0x01020408u) >> 24) & 0xfu; };
+    const int valid = min(max(nb - 16 * lane, 0), 16);             // tiles past the end: neither kind
+    const unsigned in_range = (1u << valid) - 1u;
+    const unsigned bits = nib(v.x) | (nib(v.y) << 4) | (nib(v.z) << 8) | (nib(v.w) << 12);
+    const unsigned with_work = bits & in_range, without = ~bits & in_range;
+    const int cnt = __popc(with_work);
+    const int inc = wave_inclusive_scan(cnt);
+    const int A = __builtin_amdgcn_readlane(inc, 63);
+    n_predicted = A;
+    predicted = b < A;
+    // the j-th tile with (predicted) or without work: lane L holds it
+    const int j = predicted ? xcd_contiguous(b, A) : b - A;
+    const int mine = predicted ? inc : min(16 * (lane + 1), nb) - inc;   // inclusive count of my kind
+    const unsigned kind = predicted ? with_work : without;
+    const int pos = select16(kind, max(j - (mine - (int)__popc(kind)), 0));   // meaningful in lane L only
+    const unsigned long long m = __ballot(mine > j);
+    if (m == 0ull) return xcd_contiguous(b, nb);                   // cannot happen: j < count
+    const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+    const int tile = 16 * L + __builtin_amdgcn_readlane(pos, L);
+    return tile < nb ? tile : xcd_contiguous(b, nb);
+}
+
 // The work of one block: tile `tile` of a source of `nb` tiles.
 template <bool APPLY, bool CERTIFY, int CH>
 __device__ __forceinline__ void iterate_tile(
@@ -614,51 +843,119 @@ __device__ __forceinline__ void iterate_tile(
     const float *__restrict__ sz_in, float *__restrict__ sx_out, float *__restrict__ sy_out,
     float *__restrict__ sz_out, int n, double *__restrict__ totals, double *__restrict__ deltas,
     IcpState *st, double *X_hist, double *info_hist, int iter, const CohParams &cp,
-    const PointState &ps, double *__restrict__ partials, const int tile, const int nb)
+    const PointState &ps, double *__restrict__ partials, const int fixed_tile, const int nb)
 {
     constexpr int NP = kItPoints * kItHalves;         // points per thread
     __shared__ float4 queue[kItTile];                 // {x, y, z, index in tile}
     __shared__ double red[kItThreads / 64][kNumSums];
     __shared__ int wcount[NP][kItThreads / 64];
     __shared__ double shRT[12];
+    __shared__ float4 found[kItThreads / 64][2];
 
-    const long long tile0 = (long long)tile * kItTile;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool in_place = sx_in == sx_out;
+#ifdef SVICP_TRACE
+    const unsigned long long t_entry = wall_clock64();
+#endif
 
+    // ---- the wave that solves asks for the sums before any other load ----
+    SumsInFlight sums;
+    if (APPLY && wv == 0)
+        sums = request_sums(totals + (size_t)(iter - 1) * kNumSums,
+                            deltas + (size_t)(iter - 1) * kDeltaRow);
+    // ---- which tile: fixed_tile, or (fixed_tile < 0) block blockIdx.x's place in the
+    // order that puts the tiles with work first (choose_tile) ----
+    int tile = fixed_tile;
+    bool prefetch = false;
+    if (APPLY && CERTIFY && fixed_tile < 0) {
+        bool predicted;
+        int n_predicted;
+        tile = choose_tile(reinterpret_cast<const uint4 *>(ps.active + (size_t)((iter - 1) & 1) * kFlagCap)[lane],
+                           nb, (int)blockIdx.x, predicted, n_predicted);
+        // while most tiles still have work the points move too far for the remembered
+        // correspondences to be of use
+        prefetch = predicted && 4 * n_predicted <= nb;
+    }
+    const long long tile0 = (long long)tile * kItTile;
+    // everything per point is addressed as (array + tile0)[small index]: a uniform base
+    // and a 32-bit offset per thread
+    const int tile_n = (int)min((long long)kItTile, (long long)n - tile0);   // points in this tile
+    const float *const bx_in = sx_in + tile0, *const by_in = sy_in + tile0, *const bz_in = sz_in + tile0;
+    float *const bx_out = sx_out + tile0, *const by_out = sy_out + tile0, *const bz_out = sz_out + tile0;
+    float4 *const btp = ps.tp + tile0, *const bnv = ps.nv + tile0;
+    float *const blb = ps.lb + tile0;
+
+#ifdef SVICP_TRACE
+    if (threadIdx.x == 0 && iter < kTraceIters && tile < kTraceTiles) {
+        g_trace[((size_t)iter * kTraceTiles + tile) * kTraceStamps + 0] = t_entry;
+        g_trace[((size_t)iter * kTraceTiles + tile) * kTraceStamps + 8] =
+            __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+        g_trace[((size_t)iter * kTraceTiles + tile) * kTraceStamps + 9] =
+            __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
+#endif
     // ---- A: coordinates (and the tile's old sums) are requested first, so
     // their latency runs under the solve ----
     float px[NP], py[NP], pz[NP];
     bool live[NP];
 #pragma unroll
     for (int sl = 0; sl < NP; ++sl) {
-        const long long i = tile0 + sl * kItThreads + (int)threadIdx.x;
-        live[sl] = i < n;
-        const long long ic = live[sl] ? i : 0;
-        px[sl] = sx_in[ic]; py[sl] = sy_in[ic]; pz[sl] = sz_in[ic];
+        const unsigned li = sl * kItThreads + threadIdx.x;
+        live[sl] = (int)li < tile_n;
+        const unsigned lc = live[sl] ? li : 0u;
+        px[sl] = bx_in[lc]; py[sl] = by_in[lc]; pz[sl] = bz_in[lc];
     }
-    double old_row = 0.0;
-    if (APPLY && threadIdx.x < 30) old_row = partials[(size_t)threadIdx.x * nb + tile];
     // the next iteration's delta row starts at zero (the buffer holds one row more
     // than the longest run; row 0 is cleared by the kernel that ends a run)
     if (tile == 0)
         for (int k = threadIdx.x; k < kDeltaRow; k += kItThreads)
             deltas[(size_t)(iter + 1) * kDeltaRow + k] = 0.0;
 
-    // ---- B: solve the previous iteration's system ----
+    // ---- B: the first wave solves the previous iteration's system.  Meanwhile, in a tile
+    // that is expected to have work (it had some in the iteration before), the other waves
+    // ask for their points' remembered correspondences, and their first lanes touch the
+    // lines the first wave will want, so that its own loads after the solve find them in
+    // the cache.  (Two arms of one branch: the solve's registers and the early loads'
+    // registers are never alive together.) ----
+    float4 tp[NP], nv[NP];
+    float lb[NP];
+    float touched = 0.f;
     double R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1, T0 = 0, T1 = 0,
            T2 = 0;
     if (APPLY) {
         // totals[k]: sums after iteration k - 1 (row 0 is zero); deltas[k]: changes made by iteration k
-        if (wv == 0)
-            solve_and_update(totals + (size_t)(iter - 1) * kNumSums,
-                             deltas + (size_t)(iter - 1) * kDeltaRow,
-                             totals + (size_t)iter * kNumSums, st, X_hist, info_hist, iter - 1,
-                             tile == 0, shRT);
+        if (wv == 0) {
+            solve_and_update(sums, totals + (size_t)iter * kNumSums, st, X_hist, info_hist, iter - 1,
+                             tile == 0, shRT
+#ifdef SVICP_TRACE
+                             , (iter < kTraceIters && tile < kTraceTiles)
+                                   ? g_trace + ((size_t)iter * kTraceTiles + tile) * kTraceStamps : nullptr
+#endif
+                             );
+        } else if (CERTIFY && prefetch) {
+#pragma unroll
+            for (int sl = 0; sl < NP; ++sl) {
+                const unsigned li = sl * kItThreads + threadIdx.x;
+                const unsigned lc = live[sl] ? li : 0u;
+                tp[sl] = btp[lc]; nv[sl] = bnv[lc]; lb[sl] = blb[lc];
+            }
+            // the first wave's share: per slot 64 points = 8 + 8 + 2 lines of 128 bytes
+            const int u = (int)threadIdx.x - 64;
+            if (u < NP * 18) {
+                const int sl = u / 18, line = u % 18;
+                // point whose record starts the line (records of 16, 16 and 4 bytes), kept
+                // inside the tile at the end of the source
+                const unsigned pt = min((unsigned)(sl * kItThreads + (line < 16 ? 8 * (line & 7) : 32 * (line - 16))),
+                                        (unsigned)(tile_n - 1));
+                touched = line < 8 ? btp[pt].x : line < 16 ? bnv[pt].x : blb[pt];
+            }
+        }
         __syncthreads();
         R0 = shRT[0]; R1 = shRT[1]; R2 = shRT[2]; R3 = shRT[3]; R4 = shRT[4]; R5 = shRT[5];
         R6 = shRT[6]; R7 = shRT[7]; R8 = shRT[8]; T0 = shRT[9]; T1 = shRT[10]; T2 = shRT[11];
     }
+    asm volatile("" ::"v"(touched));   // the touching loads are issued whatever the optimiser thinks of them
+    SVICP_STAMP(1);
 
     // ---- C: update (CPoint2PlaneICP.cpp:44-49) ----
     float m2[NP];                 // squared displacement of the point
@@ -679,8 +976,8 @@ __device__ __forceinline__ void iterate_tile(
             m2[sl] = moved ? mx * mx + my * my + mz * mz : 0.f;
             // in place the store can be skipped for a point that did not move
             if (live[sl] && (moved || !in_place)) {
-                const long long i = tile0 + sl * kItThreads + (int)threadIdx.x;
-                sx_out[i] = px[sl]; sy_out[i] = py[sl]; sz_out[i] = pz[sl];
+                const unsigned li = sl * kItThreads + threadIdx.x;
+                bx_out[li] = px[sl]; by_out[li] = py[sl]; bz_out[li] = pz[sl];
             }
         }
     }
@@ -691,9 +988,16 @@ __device__ __forceinline__ void iterate_tile(
     // that holds for the whole tile, its row of `partials` is still right and
     // only the coordinates had to be read.  Near convergence most tiles are
     // like that. ----
+    SVICP_STAMP(2);
+    unsigned char *const flag = ps.active ? ps.active + (size_t)(iter & 1) * kFlagCap + tile : nullptr;
     if (APPLY && CERTIFY && in_place) {
-        if (!__syncthreads_or(any_moved ? 1 : 0)) return;
+        if (!__syncthreads_or(any_moved ? 1 : 0)) {
+            if (flag && threadIdx.x == 0) *flag = 0;
+            return;
+        }
     }
+    if (flag && threadIdx.x == 0) *flag = 1;
+    SVICP_STAMP(3);
 
     double acc[30];
 #pragma unroll
@@ -710,17 +1014,17 @@ __device__ __forceinline__ void iterate_tile(
 #pragma unroll
         for (int sl = 0; sl < NP; ++sl) hopeless = hopeless && !(live[sl] && m2[sl] < cp.cov * cp.cov);
         if (__ballot(!hopeless) != 0ull) {
-            float4 tp[NP], nv[NP];
-            float lb[NP];
+            if (!prefetch || wv == 0) {
 #pragma unroll
-            for (int sl = 0; sl < NP; ++sl) {
-                const long long i = tile0 + sl * kItThreads + (int)threadIdx.x;
-                const long long ic = live[sl] ? i : 0;
-                tp[sl] = ps.tp[ic]; nv[sl] = ps.nv[ic]; lb[sl] = ps.lb[ic];
+                for (int sl = 0; sl < NP; ++sl) {
+                    const unsigned li = sl * kItThreads + threadIdx.x;
+                    const unsigned lc = live[sl] ? li : 0u;
+                    tp[sl] = btp[lc]; nv[sl] = bnv[lc]; lb[sl] = blb[lc];
+                }
             }
 #pragma unroll
             for (int sl = 0; sl < NP; ++sl) {
-                const long long i = tile0 + sl * kItThreads + (int)threadIdx.x;
+                const unsigned li = sl * kItThreads + threadIdx.x;
                 float lbn = lb[sl];
                 if (m2[sl] > 0.f) lbn = (lbn - sqrtf(m2[sl]) * kSlackUp) * kSlackDown;
                 const int pos = __float_as_int(tp[sl].w);
@@ -736,7 +1040,7 @@ __device__ __forceinline__ void iterate_tile(
                     pos >= 0 && (still || (lbn > 0.f && d2 * kSlackUp2 < lbn * lbn));
                 const bool proven_none = pos < 0 && (still || lbn > cp.root_hi);
                 need_search[sl] = live[sl] && !(proven_nn || proven_none);
-                if (live[sl] && !need_search[sl] && m2[sl] > 0.f) ps.lb[i] = lbn;
+                if (live[sl] && !need_search[sl] && m2[sl] > 0.f) blb[li] = lbn;
                 if (live[sl] && proven_nn && d2 <= cp.thr)
                     accumulate_point(acc, px[sl], py[sl], pz[sl], d2, cp.thr, tp[sl].x, tp[sl].y,
                                      tp[sl].z, nv[sl].x, nv[sl].y, nv[sl].z);
@@ -744,6 +1048,7 @@ __device__ __forceinline__ void iterate_tile(
         }
     }
 
+    SVICP_STAMP(4);
     // ---- queue of the points that need a search, in a fixed order: by slot,
     // then by thread (ballot + popcount per wave, wave totals through LDS) ----
     int my_rank[NP];
@@ -769,7 +1074,7 @@ __device__ __forceinline__ void iterate_tile(
                 px[sl], py[sl], pz[sl], __int_as_float(sl * kItThreads + (int)threadIdx.x));
         total += all;
     }
-    __syncthreads();
+    if (total > 0) __syncthreads();     // (the same in every thread)
 
     // slot 31 of the iteration's delta row counts the searched points (a statistic
     // for the caller; the solve reads slots 0..29 only)
@@ -777,12 +1082,11 @@ __device__ __forceinline__ void iterate_tile(
         atomicAdd(deltas + (size_t)iter * kDeltaRow + (tile & (kDeltaCopies - 1)) * kNumSums + 31,
                   (double)total);
 
+    SVICP_STAMP(5);
     // ---- G: search the queued points (CPoint2PlaneICP.cpp:65-67) ----
-    for (int q = threadIdx.x; q < total; q += kItThreads) {
-        const float4 e = queue[q];
-        const long long i = tile0 + __float_as_int(e.w);
-        float best, second; int bpos, bidx;
-        nn_capped<CH, true>(g, e.x, e.y, e.z, best, bpos, bidx, &second);
+    // what a search found is remembered and, inside the threshold, accumulated
+    auto settle = [&](const float4 &e, float best, int bpos, float second, auto &&target_point) {
+        const unsigned li = (unsigned)__float_as_int(e.w);
         float4 tp = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
         // a point without an accepted neighbour has every target farther than cov / kSlackUp
@@ -790,7 +1094,7 @@ __device__ __forceinline__ void iterate_tile(
         float lbn = cp.cov * kSlackDown * kSlackDown;
         if (bpos >= 0 && sqrtf(best) * kSlackUp <= cp.cov) {
             // no unprobed point can be nearer: bpos is the nearest neighbour
-            float4 t = g.pts[bpos];
+            const float4 t = target_point();
             const size_t o = 3 * (size_t)bpos;
             tp = make_float4(t.x, t.y, t.z, __int_as_float(bpos));
             nv = make_float4(g.nrm[o], g.nrm[o + 1], g.nrm[o + 2], 0.f);
@@ -798,13 +1102,46 @@ __device__ __forceinline__ void iterate_tile(
             if (best <= cp.thr)
                 accumulate_point(acc, e.x, e.y, e.z, best, cp.thr, t.x, t.y, t.z, nv.x, nv.y, nv.z);
         }
-        ps.tp[i] = tp;
-        ps.nv[i] = nv;
-        ps.lb[i] = lbn;
+        btp[li] = tp;
+        bnv[li] = nv;
+        blb[li] = lbn;
+    };
+    // a handful of points (the usual case once the registration has settled): one wave
+    // per point, the candidates spread over its lanes; the answers wait in LDS
+    const bool few = total <= kItThreads / 64;
+    if (few && total > 0) {
+        if (wv < total) {
+            const float4 e = queue[wv];
+            float best, second; int bpos, bidx;
+            float4 t;
+            nn_capped_wave<true>(g, e.x, e.y, e.z, best, bpos, bidx, t, &second);
+            if (lane == 0) {
+                found[wv][0] = make_float4(t.x, t.y, t.z, best);
+                found[wv][1] = make_float4(second, __int_as_float(bpos), 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+    }
+    for (int q = threadIdx.x; q < total; q += kItThreads) {
+        const float4 e = queue[q];
+        float best, second; int bpos, bidx;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (few) {
+            const float4 f0 = found[q][0], f1 = found[q][1];
+            t = f0; best = f0.w; second = f1.x; bpos = __float_as_int(f1.y);
+        } else {
+            nn_capped<CH, true>(g, e.x, e.y, e.z, best, bpos, bidx, &second);
+        }
+        settle(e, best, bpos, second, [&]() { return few ? t : g.pts[bpos]; });
     }
 
+    SVICP_STAMP(6);
     // ---- H: the tile's new sums replace its row; the difference goes to this
     // iteration's delta (one fp64 atomic per changed sum) ----
+    // the tile's old sums are asked for here, late: nothing else has to stay in registers
+    // for them, and the block sum covers their latency
+    double old_row = 0.0;
+    if (APPLY && threadIdx.x < 30) old_row = partials[(size_t)threadIdx.x * nb + tile];
     const double s = block_sum_30(acc, red);
     if (threadIdx.x < 30) {
         partials[(size_t)threadIdx.x * nb + tile] = s;
@@ -813,6 +1150,7 @@ __device__ __forceinline__ void iterate_tile(
             atomicAdd(deltas + (size_t)iter * kDeltaRow + (tile & (kDeltaCopies - 1)) * kNumSums +
                           threadIdx.x, d);
     }
+    SVICP_STAMP(7);
 }
 
 template <bool APPLY, bool CERTIFY, int CH>
@@ -824,9 +1162,10 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     double *__restrict__ partials)
 {
     const int nb = (int)gridDim.x;
+    const bool adaptive = APPLY && CERTIFY && ps.active != nullptr;
     iterate_tile<APPLY, CERTIFY, CH>(g, sx_in, sy_in, sz_in, sx_out, sy_out, sz_out, n, totals,
                                      deltas, st, X_hist, info_hist, iter, cp, ps, partials,
-                                     xcd_contiguous((int)blockIdx.x, nb), nb);
+                                     adaptive ? -1 : xcd_contiguous((int)blockIdx.x, nb), nb);
 }
 
 // ------------------------------------------------------------------------
@@ -886,7 +1225,8 @@ __global__ __launch_bounds__(64) void batch_solve_kernel(const BatchPair *__rest
 {
     __shared__ double rt[12];
     const BatchPair *P = pairs + blockIdx.x;
-    solve_and_update(P->totals + (size_t)iter * kNumSums, P->deltas + (size_t)iter * kDeltaRow,
+    solve_and_update(request_sums(P->totals + (size_t)iter * kNumSums,
+                                  P->deltas + (size_t)iter * kDeltaRow),
                      P->totals + (size_t)(iter + 1) * kNumSums, P->st, P->X_hist, P->info_hist, iter,
                      true, rt);
     __syncthreads();
@@ -911,7 +1251,8 @@ __global__ __launch_bounds__(64) void solve_kernel(double *totals, double *delta
                                                    double *info_hist, int iter, IcpState *host_copy)
 {
     __shared__ double rt[12];
-    solve_and_update(totals + (size_t)iter * kNumSums, deltas + (size_t)iter * kDeltaRow,
+    solve_and_update(request_sums(totals + (size_t)iter * kNumSums,
+                                  deltas + (size_t)iter * kDeltaRow),
                      totals + (size_t)(iter + 1) * kNumSums, st, X_hist, info_hist, iter, true,
                      rt);
     __syncthreads();

@@ -1,50 +1,89 @@
-"""Development probe (apply tools/trace_instrumentation.patch, build with -DSVICP_TRACE=1, point SVICP_LIBRARY at it): where does the time
-of one iteration go?  Prints, per iteration, the median over blocks of each phase boundary
-relative to the earliest block start, in microseconds."""
-import ctypes as C
-import sys
-sys.path.insert(0, ".")
+"""Development probe for -DSVICP_TRACE builds: where one iteration's time goes.
+
+Prints, per iteration, the gap to the previous launch, the span of the launch and the phase
+boundaries of the block that ends last (all in microseconds from the launch's first stamp)."""
+import ctypes, os, sys
 import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import stereovision_amd as sv
 from stereovision_amd import synth, _lib
-tgt, nrm, src, _ = synth.make_pair(1024)
-c = sv.Context(0)
-c.set_target(tgt, nrm)
-c.set_source(src)
-c.run(30)
-c.set_source(src)
-c.run(30)
-lib = _lib.load()
-buf = np.zeros((64, 1024, 8), np.uint64)
-lib.svicp_debug_trace.argtypes = [C.c_void_p]
-assert lib.svicp_debug_trace(buf.ctypes.data) == 0
-names = ["start", "solved", "moved", "certified", "queued", "searched", "done"]
-for it in (0, 1, 2, 3, 4, 5, 10, 20, 29):
-    t = buf[it, :, :7].astype(np.float64) * 0.01
-    t0 = t[:, 0].min()
-    t[t == 0] = np.nan
-    rel = t - t0
-    med = np.nanmedian(rel, axis=0)
-    mx = np.nanmax(rel, axis=0)
-    print(f"iter {it:2d} median:", " ".join(f"{n}={v:6.2f}" for n, v in zip(names, med)))
-    print(f"        max   :", " ".join(f"{n}={v:6.2f}" for n, v in zip(names, mx)))
-    if it in (20, 25):
-        tot = buf[it, :, 7].astype(np.int64)
-        skipped = np.isnan(rel[:, 6])
-        print(f"        tiles skipped: {skipped.sum()}, with queued points: {(tot > 0).sum()} (points {tot.sum()})")
-        for label, sel in (("no queued points", (~skipped) & (tot == 0)), ("queued points   ", tot > 0)):
-            if sel.any():
-                d = np.diff(rel[sel][:, :7], axis=1)
-                print(f"        {label}: phase durations median", " ".join(f"{v:5.2f}" for v in np.median(d, axis=0)),
-                      "| max", " ".join(f"{v:5.2f}" for v in d.max(axis=0)),
-                      "| done median %.2f max %.2f" % (np.median(rel[sel][:, 6]), rel[sel][:, 6].max()))
-    if it + 1 < 64:
-        nxt = buf[it + 1, :, 0].astype(np.float64) * 0.01
-        print(f"        next kernel's first block starts at {nxt.min() - t0:6.2f}")
 
-buf2 = np.zeros((64, 8), np.uint64)
-lib.svicp_debug_trace2.argtypes = [C.c_void_p]
-assert lib.svicp_debug_trace2(buf2.ctypes.data) == 0
-d = np.diff(buf2[5:29, :7].astype(np.float64) * 0.01, axis=1)
-print("solve phases (loads+sums, scaling, factorisation, back substitution, sincos, R to LDS), us:",
-      " ".join(f"{v:.2f}" for v in np.median(d, axis=0)))
+side = int(os.environ.get("SIDE", "1024"))
+iters = int(os.environ.get("ITERS", "30"))
+tgt, nrm, src, P = synth.make_pair(side)
+ctx = sv.Context(0)
+ctx.set_target(tgt, nrm)
+ctx.set_source(src)
+lib = ctypes.CDLL(_lib.LIB_PATH)
+ctx.run(iters)
+lib.svicp_debug_trace_clear()
+ctx.run(iters)
+NI, NT, NS = 64, 1024, 16
+buf = np.zeros(NI * NT * NS, dtype=np.uint64)
+lib.svicp_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+assert lib.svicp_debug_trace(buf.ctypes.data, buf.size) == 0
+raw = buf.reshape(NI, NT, NS)
+tr = raw[:, :, :8].astype(np.float64) * 0.01
+NS = 8       # 100 MHz -> microseconds
+prev_end = None
+names = ["entry", "solved", "updated", "decided", "proved", "queued", "searched", "end"]
+print("iter  gap  span | last block: " + " ".join(f"{n:>8s}" for n in names[1:]) + " | active tiles, median end of active, median 'decided' of all")
+for k in range(iters):
+    t = tr[k]
+    t0 = t[:, 0][t[:, 0] > 0].min()
+    last = np.where(t > 0, t, 0).max(axis=1)            # last stamp of each tile
+    end = last.max()
+    crit = int(last.argmax())
+    active = t[:, 7] > 0
+    row = t[crit]
+    cells = " ".join(f"{(row[j] - t0):8.2f}" if row[j] > 0 else "       -" for j in range(1, NS))
+    gap = (t0 - prev_end) if prev_end is not None else float("nan")
+    med_act = np.median(t[active, 7] - t0) if active.any() else float("nan")
+    dec = t[:, 2][t[:, 2] > 0]
+    print(f"{k:3d} {gap:5.2f} {end - t0:6.2f} | {cells} | {int(active.sum()):4d} {med_act:6.2f} {np.median(dec - t0) if dec.size else float('nan'):6.2f}"
+          f"  entry spread {np.percentile(t[:,0]-t0, 50):.2f}/{(t[:,0]-t0).max():.2f}")
+    prev_end = end
+
+# where the active tiles of a settled iteration run, and how their phases spread
+for k in (17, 25):
+    t = tr[k]
+    t0 = t[:, 0].min()
+    active = np.where(t[:, 7] > 0)[0]
+    hw = raw[k, :, 8].astype(np.int64); xcc = raw[k, :, 9].astype(np.int64) & 15
+    cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+    place = xcc * 1000 + se * 100 + sh * 10 * 2 + cu      # one number per CU
+    print(f"iteration {k}: active tiles {active.tolist()}")
+    print("  XCD of active tiles:", np.bincount(xcc[active], minlength=8).tolist())
+    per_cu = {}
+    for a in active:
+        per_cu.setdefault((int(xcc[a]), int(se[a]), int(sh[a]), int(cu[a])), []).append(int(a))
+    sizes = np.array([len(v) for v in per_cu.values()])
+    print("  CUs hosting active tiles:", len(per_cu), " active tiles per such CU: max", sizes.max(), "mean %.2f" % sizes.mean())
+    dur = np.diff(t[active][:, :8], axis=1)
+    for j, n in enumerate(names[1:]):
+        d = dur[:, j]
+        print(f"  phase -> {n:9s}: median {np.median(d):5.2f}  p90 {np.percentile(d, 90):5.2f}  max {d.max():5.2f}")
+    ends = t[active, 7] - t0
+    co = np.array([len(per_cu[(int(xcc[a]), int(se[a]), int(sh[a]), int(cu[a]))]) for a in active])
+    for c in sorted(set(co.tolist())):
+        print(f"  active tiles sharing their CU with {c - 1} other active tiles: {int((co == c).sum()):4d}, median end {np.median(ends[co == c]):.2f}, max end {ends[co == c].max():.2f}")
+
+    sv_ = raw[k][active][:, 10:15].astype(np.float64) * 0.01 - t[active][:, 0:1]
+    for j, n in enumerate(["sums loaded", "scaled", "factorised", "substituted", "R,T written"]):
+        print(f"  solve: {n:12s} at median {np.median(sv_[:, j]):5.2f}  max {sv_[:, j].max():5.2f} after entry")
+
+# how the dispatcher places blocks (iteration 0: every block does the same work)
+hw = raw[0, :, 8].astype(np.int64); xcc = raw[0, :, 9].astype(np.int64) & 15
+cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; simd = (hw >> 4) & 3; wave = hw & 15
+nb = 1024
+print("block -> (xcc, se, sh, cu) for the blocks of XCD 0 in launch order")
+line = []
+for within in range(128):
+    tile = 0 * 128 + within          # xcd_contiguous with nb = 1024: tile = xcd * 128 + within
+    line.append(f"{within}:({xcc[tile]},{se[tile]},{sh[tile]},{cu[tile]})")
+print(" ".join(line))
+for it in (0, 17):
+    hw = raw[it, :, 8].astype(np.int64); xcc = raw[it, :, 9].astype(np.int64) & 15
+    cuid = xcc * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 20 + ((hw >> 8) & 15)
+    print(f"iteration {it}: distinct CUs {len(set(cuid.tolist()))}, blocks per CU max {np.bincount(np.unique(cuid, return_inverse=True)[1]).max()}")
