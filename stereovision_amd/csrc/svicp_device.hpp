@@ -497,19 +497,6 @@ constexpr int kFlagCap = 1024;   // tiles the adaptive block order handles (16 p
 // Restates CPoint2PlaneICP.cpp:109 (X), :111-119 (R = Rz*Ry*Rx, T) and
 // :36-39 / :52-55 (Trans = [R T; 0 1] * Trans).
 // ------------------------------------------------------------------------
-// 1/sqrt(a) to fp64 accuracy: the hardware estimate (about 2^-23 relative) and two Newton
-// steps, each y <- y + (y/2) * (1 - a*y*y): 1e-7 -> 2e-14 -> rounding level.
-__device__ __forceinline__ double fast_rsqrt(double a)
-{
-    double y = __builtin_amdgcn_rsq(a);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const double e = fma(-(a * y), y, 1.0);
-        y = fma(0.5 * y, e, y);
-    }
-    return y;
-}
-
 // 2^-floor(e/2) for a = f * 2^e, 1 <= f < 2: a power of two near 1/sqrt(a).  Scaling rows
 // and columns by it is exact and leaves the diagonal in [1, 4).
 __device__ __forceinline__ double pow2_rsqrt(double a)
@@ -558,18 +545,6 @@ __device__ __forceinline__ double lane_bcast(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
-// Wave-parallel solve, called by ONE full wave (64 lanes).  The 32 sums are
-// base[] + the kDeltaCopies copies of delta[] (global memory).  Results: R (9) and T (3) to out_rt (LDS);
-// when `record`, also the sums to totals[], the state, the accumulated
-// transform and the history rows.
-//
-// Cholesky of the diagonally scaled matrix with the right-hand side carried as
-// a seventh row, so the forward substitution falls out of the factorisation.
-// Lane r (r < 7) keeps row r in registers; what other rows need of it travels
-// by lane broadcasts, so there is no LDS or memory round trip inside the
-// factorisation.  Lanes >= 7 run the same instructions on values nobody reads.
-// Restates CPoint2PlaneICP.cpp:109 (X), :111-119 (R = Rz*Ry*Rx, T) and
-// :36-39 / :52-55 (Trans = [R T; 0 1] * Trans).
 // The loads behind the running totals, issued by request_sums() and consumed by
 // solve_and_update().  Vector loads return in issue order, so the wave that solves asks
 // for these before anything else it loads.
@@ -592,13 +567,22 @@ __device__ __forceinline__ SumsInFlight request_sums(const double *base, const d
     return s;
 }
 
+// Wave-parallel solve, called by ONE full wave (64 lanes) with the sums requested by
+// request_sums().  Results: R (9) and T (3) to out_rt (LDS); when `record`, also the sums
+// to totals[], the state, the accumulated transform and the history rows.
+//
+// Gaussian elimination of the diagonally scaled, positive definite matrix.  Lane r
+// (r < 6) keeps row r and element r of the right-hand side in registers; what other rows
+// need of it travels by lane broadcasts, so there is no LDS or memory round trip inside
+// the elimination.  Lanes >= 6 run the same instructions on values nobody reads.
+// Restates CPoint2PlaneICP.cpp:109 (X), :111-119 (R = Rz*Ry*Rx, T) and
+// :36-39 / :52-55 (Trans = [R T; 0 1] * Trans).
 __device__ inline void solve_and_update(const SumsInFlight &sums, double *totals,
                                         IcpState *st, double *X_hist, double *info_hist,
                                         int iter, bool record, double *out_rt,
                                         unsigned long long *trace_row = nullptr)
 {
     const int t = threadIdx.x & 63;
-    const int row = t < 7 ? t : 6;
     bool ok = true;
 
     // running totals of the normal equations: the totals after the iteration
@@ -613,13 +597,15 @@ __device__ inline void solve_and_update(const SumsInFlight &sums, double *totals
     }
     if (record && t < kNumSums) totals[t] = stat;
     SVICP_SOLVE_STAMP(10);
+    // lane r < 6 takes row r of the matrix and element r of the right-hand side
+    const int rr6 = t < 6 ? t : 5;
     double m[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        const int lo = row < c ? row : c, hi = row < c ? c : row;
-        const int at = row < 6 ? lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo) : 21 + c;
-        m[c] = __shfl(stat, at, 64);
+        const int lo = rr6 < c ? rr6 : c, hi = rr6 < c ? c : rr6;
+        m[c] = __shfl(stat, lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo), 64);
     }
+    double rhs = __shfl(stat, 21 + rr6, 64);
 
     // scaling d ~ diag^-1/2, a power of two (exact)
     double d[6];
@@ -630,36 +616,48 @@ __device__ inline void solve_and_update(const SumsInFlight &sums, double *totals
         ok = ok && good;
         d[c] = good ? pow2_rsqrt(a) : 1.0;
     }
-    double dmine = 1.0;                     // the rhs row is scaled by the columns only
+    double dmine = 1.0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) dmine = (row == c) ? d[c] : dmine;
+    for (int c = 0; c < 6; ++c) dmine = (rr6 == c) ? d[c] : dmine;
 #pragma unroll
     for (int c = 0; c < 6; ++c) m[c] = m[c] * dmine * d[c];
+    rhs *= dmine;
 
     SVICP_SOLVE_STAMP(11);
-    double inv[6];
+    // Elimination without a division on the critical path.  Step c replaces row r > c by
+    // sigma * (p * row_r - a_rc * row_c), p the pivot: for any sigma > 0 that is the
+    // elimination step followed by a scaling of the row, which changes neither the
+    // solution nor the stability (the matrix is positive definite, no pivoting needed).
+    // sigma is the hardware's estimate of 1 / p, so the rows keep their magnitude; the
+    // dependent chain per step is estimate, two products and one fused multiply-add
+    // instead of a square root refined to full precision.
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        double lc[6];                       // row c of the factor, columns < c
+        double p = lane_bcast(m[c], c);
+        if (!(p > 1e-14) || !(p < 1e300)) { ok = false; p = 1.0; }
+        const double sigma = __builtin_amdgcn_rcp(p);
+        const bool below = rr6 > c;
+        const double ps = below ? p * sigma : 1.0;          // rows <= c stay as they are
+        const double ms = below ? m[c] * sigma : 0.0;
 #pragma unroll
-        for (int k = 0; k < c; ++k) lc[k] = lane_bcast(m[k], c);
-        double v = m[c];
-#pragma unroll
-        for (int k = 0; k < c; ++k) v = fma(-m[k], lc[k], v);
-        double piv = lane_bcast(v, c);
-        if (!(piv > 1e-14) || !(piv < 1e300)) { ok = false; piv = 1.0; }
-        inv[c] = fast_rsqrt(piv);
-        m[c] = v * inv[c];                  // lane c: sqrt(piv); lanes > c: L[r][c]; lane 6: y[c]
+        for (int k = c + 1; k < 6; ++k) m[k] = fma(-ms, lane_bcast(m[k], c), ps * m[k]);
+        rhs = fma(-ms, lane_bcast(rhs, c), ps * rhs);
     }
     SVICP_SOLVE_STAMP(12);
-    // back substitution L^T x = y
+    // lane r now holds row r of an upper triangular system; 1 / diagonal to full
+    // precision in every lane at once, then the substitution from the last row up
+    double diag = m[0];
+#pragma unroll
+    for (int c = 1; c < 6; ++c) diag = (rr6 == c) ? m[c] : diag;
+    if (!(fabs(diag) > 1e-300)) diag = 1.0;                  // (ok is already false then)
+    double inv = __builtin_amdgcn_rcp(diag);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) inv = fma(inv, fma(-diag, inv, 1.0), inv);
     double x[6];
 #pragma unroll
     for (int r = 5; r >= 0; --r) {
-        double v = lane_bcast(m[r], 6);
-#pragma unroll
-        for (int k = r + 1; k < 6; ++k) v = fma(-lane_bcast(m[r], k), x[k], v);
-        x[r] = v * inv[r];
+        x[r] = lane_bcast(rhs * inv, r);
+        if (r > 0) rhs = fma(-m[r], x[r], rhs);             // rows above take x[r] out
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r) {

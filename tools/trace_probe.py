@@ -87,3 +87,13 @@ for it in (0, 17):
     hw = raw[it, :, 8].astype(np.int64); xcc = raw[it, :, 9].astype(np.int64) & 15
     cuid = xcc * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 20 + ((hw >> 8) & 15)
     print(f"iteration {it}: distinct CUs {len(set(cuid.tolist()))}, blocks per CU max {np.bincount(np.unique(cuid, return_inverse=True)[1]).max()}")
+
+# which SIMD the first wave of each block sits on, for the blocks that share a CU
+hw = raw[17, :, 8].astype(np.int64); xcc = raw[17, :, 9].astype(np.int64) & 15
+cuid = xcc * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 20 + ((hw >> 8) & 15)
+simd = (hw >> 4) & 3
+from collections import Counter
+pat = Counter()
+for c in np.unique(cuid):
+    pat[tuple(sorted(simd[cuid == c].tolist()))] += 1
+print("SIMDs of the first waves of the blocks sharing a CU (pattern: count):", dict(pat))
