@@ -97,3 +97,22 @@ pat = Counter()
 for c in np.unique(cuid):
     pat[tuple(sorted(simd[cuid == c].tolist()))] += 1
 print("SIMDs of the first waves of the blocks sharing a CU (pattern: count):", dict(pat))
+
+# balance over the XCDs in the search-heavy iterations
+for k in range(0, 6):
+    t = tr[k]; t0 = t[:, 0].min()
+    xcc = raw[k, :, 9].astype(np.int64) & 15
+    last = np.where(t > 0, t, 0).max(axis=1) - t0
+    srch = (t[:, 6] - t[:, 5])
+    print(f"iteration {k}: per XCD max end " + " ".join(f"{last[xcc == x].max():6.2f}" for x in range(8)) +
+          "   median end " + " ".join(f"{np.median(last[xcc == x]):6.2f}" for x in range(8)) +
+          f"   search phase median {np.median(srch):.2f} p90 {np.percentile(srch, 90):.2f} max {srch.max():.2f}")
+
+print("median over tiles, microseconds after the launch's first entry: entry | sums loaded, scaled, eliminated, substituted, R,T | solved updated decided proved queued searched end")
+for k in range(1, 8):
+    t = tr[k]; t0 = t[:, 0].min()
+    act = t[:, 7] > 0
+    sv_ = raw[k][:, 10:15].astype(np.float64) * 0.01 - t0
+    ph = t[act][:, 1:8] - t0
+    print(f"  {k}: {np.median(t[:, 0] - t0):5.2f} | " + " ".join(f"{np.median(sv_[:, j]):5.2f}" for j in range(5)) + " | " +
+          " ".join(f"{np.median(ph[:, j]):5.2f}" for j in range(7)))
