@@ -1067,9 +1067,13 @@ __device__ __forceinline__ void iterate_tile(
             before += w < wv ? c : 0;
             all += c;
         }
-        if (need_search[sl])
-            queue[total + before + my_rank[sl]] = make_float4(
-                px[sl], py[sl], pz[sl], __int_as_float(sl * kItThreads + (int)threadIdx.x));
+        if (need_search[sl]) {
+            // the thread's index formed anew from the lane counter: kept from the top of the
+            // kernel it would be one more value to hold in registers across every phase
+            const int me = 64 * wv + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            queue[total + before + my_rank[sl]] =
+                make_float4(px[sl], py[sl], pz[sl], __int_as_float(sl * kItThreads + me));
+        }
         total += all;
     }
     if (total > 0) __syncthreads();     // (the same in every thread)

@@ -1,6 +1,6 @@
 """Development probe: standalone 1-NN kernel times and the loop."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import stereovision_amd as sv
 from stereovision_amd import synth
 tgt, nrm, src, _ = synth.make_pair(1024)

@@ -1,6 +1,6 @@
 """Development probe: searched points per iteration and loop time."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import stereovision_amd as sv
 from stereovision_amd import synth
