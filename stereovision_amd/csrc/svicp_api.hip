@@ -312,19 +312,19 @@ void launch_iteration(svicp_ctx *ctx, int k, double *partials)
     const int n = (int)ctx->n;
     if (k == 0) {
         hipLaunchKernelGGL((icp_iterate_kernel<false, false, 4>), grid, block, 0, ctx->stream,
-                           ctx->g, x0, y0, z0, wx, wy, wz, n, tot, del, state, xh, ih, k, cp, ps,
-                           partials);
+                           tot, del, k, n, ps.active, ps.tp, ps.nv, ps.lb, x0, y0, z0, wx, wy, wz, state, xh, ih, cp, partials,
+                           ctx->g);
         return;
     }
     const float *ix = k == 1 ? x0 : wx, *iy = k == 1 ? y0 : wy, *iz = k == 1 ? z0 : wz;
     if (ctx->opt.coherent)
         hipLaunchKernelGGL((icp_iterate_kernel<true, true, 4>), grid, block, 0, ctx->stream,
-                           ctx->g, ix, iy, iz, wx, wy, wz, n, tot, del, state, xh, ih, k, cp, ps,
-                           partials);
+                           tot, del, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, xh, ih, cp, partials,
+                           ctx->g);
     else
         hipLaunchKernelGGL((icp_iterate_kernel<true, false, 4>), grid, block, 0, ctx->stream,
-                           ctx->g, ix, iy, iz, wx, wy, wz, n, tot, del, state, xh, ih, k, cp, ps,
-                           partials);
+                           tot, del, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, xh, ih, cp, partials,
+                           ctx->g);
 }
 
 int enqueue_loop(svicp_ctx *ctx, int iters, bool timed)

@@ -1157,13 +1157,17 @@ __device__ __forceinline__ void iterate_tile(
 
 template <bool APPLY, bool CERTIFY, int CH>
 __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
-    GridDesc g, const float *__restrict__ sx_in, const float *__restrict__ sy_in,
+    // what the first loads of a launch need comes first
+    double *__restrict__ totals, double *__restrict__ deltas, int iter, int n,
+    unsigned char *ps_active, float4 *ps_tp, float4 *ps_nv, float *ps_lb,   // a PointState, member by member
+    const float *__restrict__ sx_in, const float *__restrict__ sy_in,
     const float *__restrict__ sz_in, float *__restrict__ sx_out, float *__restrict__ sy_out,
-    float *__restrict__ sz_out, int n, double *__restrict__ totals, double *__restrict__ deltas,
-    IcpState *st, double *X_hist, double *info_hist, int iter, CohParams cp, PointState ps,
-    double *__restrict__ partials)
+    float *__restrict__ sz_out, IcpState *st, double *X_hist, double *info_hist, CohParams cp,
+    double *__restrict__ partials, GridDesc g)
 {
     const int nb = (int)gridDim.x;
+    PointState ps;
+    ps.tp = ps_tp; ps.nv = ps_nv; ps.lb = ps_lb; ps.active = ps_active;
     const bool adaptive = APPLY && CERTIFY && ps.active != nullptr;
     iterate_tile<APPLY, CERTIFY, CH>(g, sx_in, sy_in, sz_in, sx_out, sy_out, sz_out, n, totals,
                                      deltas, st, X_hist, info_hist, iter, cp, ps, partials,
