@@ -329,6 +329,33 @@ def test_one_million_points_properties(ctx):
     assert np.abs(T[:3, 3] - T2[:3, 3]).max() < 1e-6
 
 
+@pytest.mark.parametrize("side,extra", [(1024, 0), (195, 11), (40, 3)])
+def test_block_order_takes_every_tile_once(ctx, side, extra):
+    """Once few tiles still have work, the tiles that had some take the first blocks of the
+    next launch.  Whatever the order, every tile has to be taken exactly once: the sums, the
+    inlier counts and the increments must equal those of a run without the shortcuts (where
+    the order is fixed and every point is searched), on a full-size pair (1024 tiles), a
+    ragged one (38 tiles, the last one partial) and a small one, and again on the same
+    context after a source of another size."""
+    from stereovision_amd import synth
+    tgt, nrm, src, _ = synth.make_pair(side)
+    src = src[: len(src) - extra] if extra else src
+    ctx.set_target(tgt, nrm)
+    runs = []
+    for coh, s in ((0, src), (1, src), (1, src[: len(src) // 3]), (1, src)):
+        ctx.set_options(coherent=coh)
+        ctx.set_source(np.ascontiguousarray(s))
+        T, info = ctx.run(30)
+        X, I = ctx.history()
+        runs.append((T, X, I))
+    ctx.set_options(coherent=1)
+    (T0, X0, I0), (T1, X1, I1), _, (T3, X3, I3) = runs
+    for T, X, I in ((T1, X1, I1), (T3, X3, I3)):
+        assert np.array_equal(I0[:, 0], I[:, 0])                   # inliers, every iteration
+        assert np.abs(X0 - X).max() < 1e-10 and np.abs(T0 - T).max() < 1e-10
+        assert np.abs(I0[:, 3] - I[:, 3]).max() <= 1e-9 * I0[:, 3].max()   # sums of weights
+
+
 def test_exact_and_capped_search_agree_within_threshold(ctx, po):
     from stereovision_amd import synth
     tgt, nrm, src, _ = synth.make_pair(128)
