@@ -235,7 +235,10 @@ int run_nn1(svicp_ctx *ctx, bool exact)
         LAUNCHCHK("nn1_kernel");
     } else {
         HIPCHK(hipMemsetAsync(ctx->n_unres.p, 0, sizeof(int), ctx->stream));
-        hipLaunchKernelGGL((nn1_kernel<true, 4>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
+        // one chunk of 256 queries per block: the far queries, which take long, come in
+        // stretches, and the dispatcher spreads them best when the blocks are small
+        const int grid_exact = (int)std::min<int64_t>(cdiv(n, kBlockThreads), 1 << 20);
+        hipLaunchKernelGGL((nn1_kernel<true, 4>), dim3(grid_exact), dim3(kBlockThreads), 0, ctx->stream,
                            ctx->g, x, y, z, perm, (int)n, ctx->opt.dist_threshold,
                            ctx->knn_idx.as<int>(), ctx->knn_d2.as<float>(),
                            ctx->unresolved.as<int>(), ctx->n_unres.as<int>());
@@ -697,8 +700,9 @@ int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n)
                 void *before = ctx->perm.p;
                 HIPCHK(ctx->perm.reserve(sizeof(int) * nn));
                 if (ctx->perm.p != before) drop_graph(ctx);
-                HIPCHK(hipMemcpyAsync(ctx->perm.p, ctx->vals_b.p, sizeof(int) * n,
-                                      hipMemcpyDeviceToDevice, ctx->stream));
+                hipLaunchKernelGGL(deal_tiles_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
+                                   ctx->vals_b.as<int>(), (int)n, ctx->perm.as<int>());
+                LAUNCHCHK("deal_tiles_kernel");
                 perm = ctx->perm.as<int>();
                 ctx->sorted = true;
             }

@@ -1316,8 +1316,19 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
     int *__restrict__ idx_out, float *__restrict__ d2_out, int *__restrict__ unresolved,
     int *__restrict__ n_unresolved)
 {
-    for (long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x; i < n;
-         i += (long long)gridDim.x * kBlockThreads) {
+    // Capped search: a block takes consecutive chunks of 256 queries, and the blocks of one
+    // XCD (blockIdx % 8 equal) consecutive blocks' worth, so each XCD's L2 sees one stretch of
+    // the source, as in the iteration kernel.  Exact search: chunks dealt out one by one; its
+    // time goes to the queries far from the target, which come in stretches, and they are
+    // better spread over all blocks.
+    const long long chunks = ((long long)n + kBlockThreads - 1) / kBlockThreads;
+    const long long per_block = (chunks + gridDim.x - 1) / gridDim.x;
+    const long long first = EXACT ? (long long)blockIdx.x
+                                  : (long long)xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * per_block;
+    const long long last = EXACT ? chunks : (first + per_block < chunks ? first + per_block : chunks);
+    for (long long c = first; c < last; c += EXACT ? (long long)gridDim.x : 1) {
+        const long long i = c * kBlockThreads + threadIdx.x;
+        if (i >= n) break;
         float qx = qx_[i], qy = qy_[i], qz = qz_[i];
         float best; int bpos, bidx;
         nn_capped<CH>(g, qx, qy, qz, best, bpos, bidx);
@@ -1750,6 +1761,29 @@ __global__ void morton_key_kernel(const float *__restrict__ aos, int n, float ox
     keys[i] = spread21(q(aos[3 * (size_t)i], ox)) | (spread21(q(aos[3 * (size_t)i + 1], oy)) << 1) |
               (spread21(q(aos[3 * (size_t)i + 2], oz)) << 2);
     vals[i] = i;
+}
+
+// Storage order of the source: Morton order, with the full 1024-point tiles dealt out so
+// that the contiguous stretch of tiles an XCD works on (xcd_contiguous) is made of groups
+// of 16 Morton-neighbouring tiles taken from all over the cloud, every eighth group.
+// Where only part of the source lies near the target, the XCDs then share the searching
+// instead of the one that owns that part doing most of it; inside a group the tiles stay
+// neighbours, which is what the L2 needs.  sorted[p]: original index of the point at Morton
+// position p; perm[q]: original index of the point stored at q.
+constexpr int kDealGroup = 16;
+__global__ void deal_tiles_kernel(const int *__restrict__ sorted, int n, int *__restrict__ perm)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int tile = p / kItTile, o = p % kItTile;
+    const int whole = (n / kItTile) & ~(8 * kDealGroup - 1);   // full tiles, in rounds of 8 groups
+    int q = p;
+    if (tile < whole) {
+        const int group = tile / kDealGroup, r = tile % kDealGroup;
+        const int xcd = group & 7, k = (group >> 3) * kDealGroup + r;
+        q = (xcd * (whole >> 3) + k) * kItTile + o;
+    }
+    perm[q] = sorted[p];
 }
 
 __global__ void iota_kernel(int *__restrict__ vals, int n)
