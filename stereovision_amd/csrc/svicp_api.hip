@@ -313,21 +313,18 @@ void launch_iteration(svicp_ctx *ctx, int k, double *partials)
     double *xh = ctx->xhist.as<double>(), *ih = ctx->ihist.as<double>();
     const dim3 grid(ctx->nb), block(kItThreads);
     const int n = (int)ctx->n;
-    if (k == 0) {
-        hipLaunchKernelGGL((icp_iterate_kernel<false, false, 4>), grid, block, 0, ctx->stream,
-                           tot, del, k, n, ps.active, ps.tp, ps.nv, ps.lb, x0, y0, z0, wx, wy, wz, state, xh, ih, cp, partials,
-                           ctx->g);
-        return;
-    }
-    const float *ix = k == 1 ? x0 : wx, *iy = k == 1 ? y0 : wy, *iz = k == 1 ? z0 : wz;
-    if (ctx->opt.coherent)
-        hipLaunchKernelGGL((icp_iterate_kernel<true, true, 4>), grid, block, 0, ctx->stream,
-                           tot, del, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, xh, ih, cp, partials,
-                           ctx->g);
-    else
-        hipLaunchKernelGGL((icp_iterate_kernel<true, false, 4>), grid, block, 0, ctx->stream,
-                           tot, del, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, xh, ih, cp, partials,
-                           ctx->g);
+#define SVICP_ITERATE(APPLY, CERTIFY, INPLACE, ix, iy, iz)                                        \
+    hipLaunchKernelGGL((icp_iterate_kernel<APPLY, CERTIFY, 4, INPLACE>), grid, block, 0, ctx->stream, \
+                       tot, del, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, \
+                       xh, ih, cp, partials, ctx->g)
+    // iteration 0 reads the source as set and moves nothing, iteration 1 reads it and writes
+    // the moving copy, later ones update the moving copy where it is
+    if (k == 0) SVICP_ITERATE(false, false, false, x0, y0, z0);
+    else if (k == 1 && ctx->opt.coherent) SVICP_ITERATE(true, true, false, x0, y0, z0);
+    else if (k == 1) SVICP_ITERATE(true, false, false, x0, y0, z0);
+    else if (ctx->opt.coherent) SVICP_ITERATE(true, true, true, wx, wy, wz);
+    else SVICP_ITERATE(true, false, true, wx, wy, wz);
+#undef SVICP_ITERATE
 }
 
 int enqueue_loop(svicp_ctx *ctx, int iters, bool timed)

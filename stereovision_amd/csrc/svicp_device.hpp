@@ -835,11 +835,13 @@ __device__ __forceinline__ int choose_tile(const uint4 v, int nb, int b, bool &p
 }
 
 // The work of one block: tile `tile` of a source of `nb` tiles.
-template <bool APPLY, bool CERTIFY, int CH>
+// INPLACE: the coordinates are updated where they are read (s?_in are not looked at); else
+// s?_in and s?_out may still be the same arrays (the batch decides per launch).
+template <bool APPLY, bool CERTIFY, int CH, bool INPLACE = false>
 __device__ __forceinline__ void iterate_tile(
-    const GridDesc &g, const float *__restrict__ sx_in, const float *__restrict__ sy_in,
-    const float *__restrict__ sz_in, float *__restrict__ sx_out, float *__restrict__ sy_out,
-    float *__restrict__ sz_out, int n, double *__restrict__ totals, double *__restrict__ deltas,
+    const GridDesc &g, const float *sx_in_, const float *sy_in_, const float *sz_in_,
+    float *sx_out, float *sy_out, float *sz_out, int n, double *__restrict__ totals,
+    double *__restrict__ deltas,
     IcpState *st, double *X_hist, double *info_hist, int iter, const CohParams &cp,
     const PointState &ps, double *__restrict__ partials, const int fixed_tile, const int nb)
 {
@@ -851,7 +853,9 @@ __device__ __forceinline__ void iterate_tile(
     __shared__ float4 found[kItThreads / 64][2];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool in_place = sx_in == sx_out;
+    const float *const sx_in = INPLACE ? sx_out : sx_in_, *const sy_in = INPLACE ? sy_out : sy_in_,
+                *const sz_in = INPLACE ? sz_out : sz_in_;
+    const bool in_place = INPLACE || sx_in == sx_out;
 #ifdef SVICP_TRACE
     const unsigned long long t_entry = wall_clock64();
 #endif
@@ -1155,23 +1159,23 @@ __device__ __forceinline__ void iterate_tile(
     SVICP_STAMP(7);
 }
 
-template <bool APPLY, bool CERTIFY, int CH>
+template <bool APPLY, bool CERTIFY, int CH, bool INPLACE>
 __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     // what the first loads of a launch need comes first
     double *__restrict__ totals, double *__restrict__ deltas, int iter, int n,
     unsigned char *ps_active, float4 *ps_tp, float4 *ps_nv, float *ps_lb,   // a PointState, member by member
-    const float *__restrict__ sx_in, const float *__restrict__ sy_in,
-    const float *__restrict__ sz_in, float *__restrict__ sx_out, float *__restrict__ sy_out,
-    float *__restrict__ sz_out, IcpState *st, double *X_hist, double *info_hist, CohParams cp,
+    const float *sx_in, const float *sy_in, const float *sz_in, float *sx_out, float *sy_out,
+    float *sz_out, IcpState *st, double *X_hist, double *info_hist, CohParams cp,
     double *__restrict__ partials, GridDesc g)
 {
     const int nb = (int)gridDim.x;
     PointState ps;
     ps.tp = ps_tp; ps.nv = ps_nv; ps.lb = ps_lb; ps.active = ps_active;
     const bool adaptive = APPLY && CERTIFY && ps.active != nullptr;
-    iterate_tile<APPLY, CERTIFY, CH>(g, sx_in, sy_in, sz_in, sx_out, sy_out, sz_out, n, totals,
-                                     deltas, st, X_hist, info_hist, iter, cp, ps, partials,
-                                     adaptive ? -1 : xcd_contiguous((int)blockIdx.x, nb), nb);
+    iterate_tile<APPLY, CERTIFY, CH, INPLACE>(g, sx_in, sy_in, sz_in, sx_out, sy_out, sz_out, n,
+                                              totals, deltas, st, X_hist, info_hist, iter, cp, ps,
+                                              partials,
+                                              adaptive ? -1 : xcd_contiguous((int)blockIdx.x, nb), nb);
 }
 
 // ------------------------------------------------------------------------
@@ -1765,12 +1769,13 @@ __global__ void morton_key_kernel(const float *__restrict__ aos, int n, float ox
 
 // Storage order of the source: Morton order, with the full 1024-point tiles dealt out so
 // that the contiguous stretch of tiles an XCD works on (xcd_contiguous) is made of groups
-// of 16 Morton-neighbouring tiles taken from all over the cloud, every eighth group.
+// of 8 Morton-neighbouring tiles taken from all over the cloud, every eighth group (4, 16
+// and 32 per group measured within 1 % of it).
 // Where only part of the source lies near the target, the XCDs then share the searching
 // instead of the one that owns that part doing most of it; inside a group the tiles stay
 // neighbours, which is what the L2 needs.  sorted[p]: original index of the point at Morton
 // position p; perm[q]: original index of the point stored at q.
-constexpr int kDealGroup = 16;
+constexpr int kDealGroup = 8;
 __global__ void deal_tiles_kernel(const int *__restrict__ sorted, int n, int *__restrict__ perm)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
