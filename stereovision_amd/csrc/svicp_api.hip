@@ -302,8 +302,8 @@ void launch_iteration(svicp_ctx *ctx, int k, double *partials)
     cp.root_hi = std::sqrt(thr) * 1.00001f;
     cp.cov = std::sqrt(thr) * 1.001f;   // inside the probe radius rr = sqrt(thr) * 1.002 + slack
     PointState ps;
-    ps.tp = ctx->st_tp.as<float4>();
-    ps.nv = ctx->st_nv.as<float4>();
+    ps.tp = ctx->st_tp.as<Float3>();
+    ps.nv = ctx->st_nv.as<Float3>();
     ps.lb = ctx->st_lb.as<float>();
     ps.active = ctx->nb <= kFlagCap ? ctx->tile_flags.as<unsigned char>() : nullptr;
     float *wx = ctx->wx.as<float>(), *wy = ctx->wy.as<float>(), *wz = ctx->wz.as<float>();
@@ -1178,7 +1178,7 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
         P.cp.thr = thr;
         P.cp.root_hi = std::sqrt(thr) * 1.00001f;
         P.cp.cov = std::sqrt(thr) * 1.001f;
-        P.ps.tp = c->st_tp.as<float4>(); P.ps.nv = c->st_nv.as<float4>(); P.ps.lb = c->st_lb.as<float>();
+        P.ps.tp = c->st_tp.as<Float3>(); P.ps.nv = c->st_nv.as<Float3>(); P.ps.lb = c->st_lb.as<float>();
         P.ps.active = nullptr;   // the batch has its own block table
         P.partials = c->partials.as<double>();
         for (int t = 0; t < c->nb; ++t) map.push_back(make_int2(i, t));

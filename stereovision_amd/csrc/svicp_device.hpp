@@ -478,13 +478,15 @@ struct CohParams {
 };
 
 // What the loop remembers about each source point between iterations
-// (arrays in source order): the matched target point and its index in the
-// sorted target (-1: no target point within cov), the matched normal, and lb,
-// a lower bound on the distance from the source point to every OTHER target
-// point.
+// (arrays in source order, 28 bytes per point): the matched target point (none within cov:
+// NaN), the matched normal, and lb, a lower bound on the distance from the source point to
+// every OTHER target point.
+struct Float3 {
+    float x, y, z;    // 12 bytes, read and written as one three-dword access
+};
 struct PointState {
-    float4 *tp;       // {tx, ty, tz, pos as int bits}
-    float4 *nv;       // {nx, ny, nz, unused}
+    Float3 *tp;       // matched target point; x is NaN when there is none within cov
+    Float3 *nv;       // its normal
     float *lb;
     // [2][kFlagCap] bytes or null: bit 0 of byte t of row (k & 1) says whether tile t had
     // work to do in iteration k (see choose_tile)
@@ -884,7 +886,7 @@ __device__ __forceinline__ void iterate_tile(
     const int tile_n = (int)min((long long)kItTile, (long long)n - tile0);   // points in this tile
     const float *const bx_in = sx_in + tile0, *const by_in = sy_in + tile0, *const bz_in = sz_in + tile0;
     float *const bx_out = sx_out + tile0, *const by_out = sy_out + tile0, *const bz_out = sz_out + tile0;
-    float4 *const btp = ps.tp + tile0, *const bnv = ps.nv + tile0;
+    Float3 *const btp = ps.tp + tile0, *const bnv = ps.nv + tile0;
     float *const blb = ps.lb + tile0;
 
 #ifdef SVICP_TRACE
@@ -919,7 +921,7 @@ __device__ __forceinline__ void iterate_tile(
     // lines the first wave will want, so that its own loads after the solve find them in
     // the cache.  (Two arms of one branch: the solve's registers and the early loads'
     // registers are never alive together.) ----
-    float4 tp[NP], nv[NP];
+    Float3 tp[NP], nv[NP];
     float lb[NP];
     float touched = 0.f;
     double R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1, T0 = 0, T1 = 0,
@@ -941,12 +943,13 @@ __device__ __forceinline__ void iterate_tile(
                 const unsigned lc = live[sl] ? li : 0u;
                 tp[sl] = btp[lc]; nv[sl] = bnv[lc]; lb[sl] = blb[lc];
             }
-            // the first wave's share: per slot 64 points = 8 + 8 + 2 lines of 128 bytes
+            // the first wave's share: per slot 64 points = 6 + 6 + 2 lines of 128 bytes (a few
+            // more where the 768-byte stretches straddle lines: one touch every 96 bytes)
             const int u = (int)threadIdx.x - 64;
             if (u < NP * 18) {
                 const int sl = u / 18, line = u % 18;
-                // point whose record starts the line (records of 16, 16 and 4 bytes), kept
-                // inside the tile at the end of the source
+                // a point every 8 records of 12 bytes, every 32 of 4; kept inside the tile at
+                // the end of the source
                 const unsigned pt = min((unsigned)(sl * kItThreads + (line < 16 ? 8 * (line & 7) : 32 * (line - 16))),
                                         (unsigned)(tile_n - 1));
                 touched = line < 8 ? btp[pt].x : line < 16 ? bnv[pt].x : blb[pt];
@@ -1029,7 +1032,7 @@ __device__ __forceinline__ void iterate_tile(
                 const unsigned li = sl * kItThreads + threadIdx.x;
                 float lbn = lb[sl];
                 if (m2[sl] > 0.f) lbn = (lbn - sqrtf(m2[sl]) * kSlackUp) * kSlackDown;
-                const int pos = __float_as_int(tp[sl].w);
+                const bool has = tp[sl].x == tp[sl].x;          // a neighbour is remembered
                 float dx = px[sl] - tp[sl].x, dy = py[sl] - tp[sl].y, dz = pz[sl] - tp[sl].z;
                 float d2 = __fmul_rn(dx, dx);
                 d2 = __fadd_rn(d2, __fmul_rn(dy, dy));
@@ -1039,8 +1042,8 @@ __device__ __forceinline__ void iterate_tile(
                 // at this very position established, near-ties included
                 const bool still = m2[sl] == 0.f;
                 const bool proven_nn =
-                    pos >= 0 && (still || (lbn > 0.f && d2 * kSlackUp2 < lbn * lbn));
-                const bool proven_none = pos < 0 && (still || lbn > cp.root_hi);
+                    has && (still || (lbn > 0.f && d2 * kSlackUp2 < lbn * lbn));
+                const bool proven_none = !has && (still || lbn > cp.root_hi);
                 need_search[sl] = live[sl] && !(proven_nn || proven_none);
                 if (live[sl] && !need_search[sl] && m2[sl] > 0.f) blb[li] = lbn;
                 if (live[sl] && proven_nn && d2 <= cp.thr)
@@ -1093,8 +1096,8 @@ __device__ __forceinline__ void iterate_tile(
     // what a search found is remembered and, inside the threshold, accumulated
     auto settle = [&](const float4 &e, float best, int bpos, float second, auto &&target_point) {
         const unsigned li = (unsigned)__float_as_int(e.w);
-        float4 tp = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+        Float3 tp = { __int_as_float(0x7fc00000), 0.f, 0.f };   // NaN: no neighbour
+        Float3 nv = { 0.f, 0.f, 0.f };
         // a point without an accepted neighbour has every target farther than cov / kSlackUp
         // (computed), hence farther than cov * kSlackDown^2 in truth
         float lbn = cp.cov * kSlackDown * kSlackDown;
@@ -1102,8 +1105,8 @@ __device__ __forceinline__ void iterate_tile(
             // no unprobed point can be nearer: bpos is the nearest neighbour
             const float4 t = target_point();
             const size_t o = 3 * (size_t)bpos;
-            tp = make_float4(t.x, t.y, t.z, __int_as_float(bpos));
-            nv = make_float4(g.nrm[o], g.nrm[o + 1], g.nrm[o + 2], 0.f);
+            tp = { t.x, t.y, t.z };
+            nv = { g.nrm[o], g.nrm[o + 1], g.nrm[o + 2] };
             lbn = fminf(sqrtf(second) * kSlackDown, lbn);
             if (best <= cp.thr)
                 accumulate_point(acc, e.x, e.y, e.z, best, cp.thr, t.x, t.y, t.z, nv.x, nv.y, nv.z);
@@ -1163,7 +1166,7 @@ template <bool APPLY, bool CERTIFY, int CH, bool INPLACE>
 __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     // what the first loads of a launch need comes first
     double *__restrict__ totals, double *__restrict__ deltas, int iter, int n,
-    unsigned char *ps_active, float4 *ps_tp, float4 *ps_nv, float *ps_lb,   // a PointState, member by member
+    unsigned char *ps_active, Float3 *ps_tp, Float3 *ps_nv, float *ps_lb,   // a PointState, member by member
     const float *sx_in, const float *sy_in, const float *sz_in, float *sx_out, float *sy_out,
     float *sz_out, IcpState *st, double *X_hist, double *info_hist, CohParams cp,
     double *__restrict__ partials, GridDesc g)
