@@ -63,7 +63,7 @@ struct svicp_ctx {
     bool have_target = false;
     GridDesc g{};
     int nranked = 0;
-    DevBuf tgt_aos, nrm_aos, pts, nrm, dir, run2, end1;
+    DevBuf tgt_aos, nrm_aos, pts, nrm, dir, run2, end1, quad;
 
     // source
     int64_t n = 0;
@@ -422,7 +422,7 @@ int svicp_destroy(svicp_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     drop_graph(ctx);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
-    DevBuf *bufs[] = { &ctx->tgt_aos, &ctx->nrm_aos, &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->run2,
+    DevBuf *bufs[] = { &ctx->tgt_aos, &ctx->nrm_aos, &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->run2, &ctx->quad,
                        &ctx->end1, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx, &ctx->wy, &ctx->wz,
                        &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->tile_flags, &ctx->perm, &ctx->tmp_aos, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
                        &ctx->vals_b, &ctx->marks, &ctx->ranks, &ctx->block_of_rank,
@@ -555,7 +555,7 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
     HIPCHK(ctx->marks.reserve(sizeof(int) * nbt));
     HIPCHK(ctx->ranks.reserve(sizeof(int) * nbt));
     HIPCHK(ctx->dir.reserve(sizeof(int) * nbt));
-    HIPCHK(ctx->block_of_rank.reserve(sizeof(int) * std::min<long long>(nbt, 2 * mm)));
+    HIPCHK(ctx->block_of_rank.reserve(sizeof(int) * std::min<long long>(nbt, 8 * mm)));   // a point marks up to 8 blocks
     HIPCHK(hipMemsetAsync(ctx->marks.p, 0, sizeof(int) * nbt, ctx->stream));
     int nranked = 0;
     if (m > 0) {
@@ -595,16 +595,18 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
     LAUNCHCHK("finish_dir_kernel");
     HIPCHK(ctx->run2.reserve(sizeof(uint2) * 64 * std::max(nranked, 1)));
     HIPCHK(ctx->end1.reserve(sizeof(unsigned) * 64 * std::max(nranked, 1)));
+    HIPCHK(ctx->quad.reserve(sizeof(uint4) * 2 * 64 * std::max(nranked, 1)));
     if (nranked > 0) {
         hipLaunchKernelGGL(fill_cells_kernel, dim3(cdiv((long long)nranked * 64, 256)), dim3(256), 0,
                            ctx->stream, g, ctx->keys_b.as<unsigned long long>(), (int)m,
                            ctx->block_of_rank.as<int>(), nranked, ctx->run2.as<uint2>(),
-                           ctx->end1.as<unsigned>());
+                           ctx->end1.as<unsigned>(), ctx->quad.as<uint4>());
         LAUNCHCHK("fill_cells_kernel");
     }
     g.dir = ctx->dir.as<int>();
     g.run2 = ctx->run2.as<uint2>();
     g.end1 = ctx->end1.as<unsigned>();
+    g.quad = ctx->quad.as<uint4>();
     g.pts = ctx->pts.as<float4>();
     g.nrm = ctx->nrm.as<float>();
     ctx->g = g;

@@ -8,10 +8,16 @@
 //              4x4x4 blocks; `dir` maps a block to its rank among the blocks
 //              that hold (or precede in x) a point, -1 otherwise.  Per ranked
 //              block 64 entries: run2 = {first point of the cell, end of the
-//              NEXT cell in x} and end1 = end of the cell itself.
+//              NEXT cell in x} and end1 = end of the cell itself; quad = the run2
+//              of the cell and of its neighbours in y, in z and in both, the
+//              four runs of a 2x2x2 probe that starts at the cell, in two
+//              16-byte words (one table look-up and two loads per probe instead
+//              of four and four).
 //   source   : SoA x[], y[], z[] in Morton order (perm[] maps back).
 //
 // A query probes the 2x2x2 cells that cover its search cube: four 2-cell runs.
+// A block is ranked when a probe that starts in it can meet a point: it holds a
+// point, or a cell one step below a point's cell in x, y and/or z.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -68,6 +74,7 @@ struct GridDesc {
     const int *dir;          // [nbz][nby][nbx]
     const uint2 *run2;       // [ranked blocks * 64]
     const unsigned *end1;    // [ranked blocks * 64]
+    const uint4 *quad;       // [ranked blocks * 64][2]: the four runs a probe from this cell walks
     const float4 *pts;       // [m] sorted
     const float *nrm;        // [3 m] sorted
 };
@@ -204,25 +211,23 @@ __device__ __forceinline__ void nn_capped(const GridDesc &g, float qx, float qy,
     int cx, cy, cz;
     if (!probe_origin(g, qx, qy, qz, cx, cy, cz)) return;
 
-    int rank[4];
+    // run r covers the cells (cx .. cx + 1, cy + (r & 1), cz + (r >> 1))
+    const int rank = g.dir[dir_index(g, cx, cy, cz)];
+    // an unranked block has no entry: read entry 0 of the table and drop it
+    const size_t e = rank >= 0 ? (size_t)rank * 64 + cell_local(cx, cy, cz) : 0;
+    const uint4 a = g.quad[2 * e], b = g.quad[2 * e + 1];
+    uint2 run[4] = { make_uint2(a.x, a.y), make_uint2(a.z, a.w), make_uint2(b.x, b.y),
+                     make_uint2(b.z, b.w) };
+    if (rank < 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        rank[r] = g.dir[dir_index(g, cx, cy + (r & 1), cz + (r >> 1))];
-    uint2 run[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        // an unranked block has no entry: read entry 0 of the table and drop it
-        int e = rank[r] >= 0 ? rank[r] * 64 + cell_local(cx, cy + (r & 1), cz + (r >> 1)) : 0;
-        uint2 v = g.run2[e];
-        run[r] = rank[r] >= 0 ? v : make_uint2(0u, 0u);
+        for (int r = 0; r < 4; ++r) run[r] = make_uint2(0u, 0u);
     }
     scan_runs<CH, SECOND>(run, qx, qy, qz, [&](unsigned j) { return g.pts[j]; }, best, bpos, bidx,
                           second);
 }
 
-// The same search by one whole wave for ONE query (all lanes pass the same q): the four
-// table look-ups run on four lanes, the candidates are spread over the lanes, and a
-// butterfly picks the winner.  Same candidates, same distance arithmetic and the same
+// The same search by one whole wave for ONE query (all lanes pass the same q): the
+// candidates are spread over the lanes, and a butterfly picks the winner.  Same candidates, same distance arithmetic and the same
 // order rule as nn_capped, so the same answer; the chain of dependent loads is table,
 // run, candidates instead of one load per chunk of candidates.  `bpt` is the winning
 // target point.  Results are uniform over the wave.
@@ -236,17 +241,13 @@ __device__ __forceinline__ void nn_capped_wave(const GridDesc &g, float qx, floa
     if (SECOND) *second = INFINITY;
     int cx, cy, cz;
     if (!probe_origin(g, qx, qy, qz, cx, cy, cz)) return;
-    const int lane = threadIdx.x & 63, r = lane & 3;
-    const int rank = g.dir[dir_index(g, cx, cy + (r & 1), cz + (r >> 1))];
-    const int e = rank >= 0 ? rank * 64 + cell_local(cx, cy + (r & 1), cz + (r >> 1)) : 0;
-    uint2 mine = g.run2[e];
-    if (rank < 0) mine = make_uint2(0u, 0u);
-    uint2 run[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        run[k].x = (unsigned)__builtin_amdgcn_readlane((int)mine.x, k);
-        run[k].y = (unsigned)__builtin_amdgcn_readlane((int)mine.y, k);
-    }
+    const int lane = threadIdx.x & 63;
+    const int rank = g.dir[dir_index(g, cx, cy, cz)];       // the same address in every lane
+    if (rank < 0) return;
+    const size_t e = (size_t)rank * 64 + cell_local(cx, cy, cz);
+    const uint4 a = g.quad[2 * e], b = g.quad[2 * e + 1];
+    const uint2 run[4] = { make_uint2(a.x, a.y), make_uint2(a.z, a.w), make_uint2(b.x, b.y),
+                           make_uint2(b.z, b.w) };
     const unsigned P1 = run[0].y - run[0].x;
     const unsigned P2 = P1 + (run[1].y - run[1].x);
     const unsigned P3 = P2 + (run[2].y - run[2].x);
@@ -1135,7 +1136,7 @@ __device__ __forceinline__ void iterate_tile(
         const float4 e = queue[q];
         float best, second; int bpos, bidx;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (few) {
+        if (__builtin_expect(few, 1)) {     // the searching case tolerates being the far branch
             const float4 f0 = found[q][0], f1 = found[q][1];
             t = f0; best = f0.w; second = f1.x; bpos = __float_as_int(f1.y);
         } else {
@@ -1668,7 +1669,8 @@ __global__ void cell_key_kernel(GridDesc g, const float *__restrict__ aos, int m
     vals[i] = i;
 }
 
-// marks the block of every occupied cell and of its x-predecessor
+// marks the block of every occupied cell and of the cells one step below it in x, y
+// and/or z: the cells from which a 2x2x2 probe reaches it
 __global__ void mark_blocks_kernel(GridDesc g, const unsigned long long *__restrict__ keys, int m,
                                    int *__restrict__ marks)
 {
@@ -1679,8 +1681,11 @@ __global__ void mark_blocks_kernel(GridDesc g, const unsigned long long *__restr
     int cx = (int)(key % g.nx);
     unsigned long long rest = key / g.nx;
     int cy = (int)(rest % g.ny), cz = (int)(rest / g.ny);
-    marks[dir_index(g, cx, cy, cz)] = 1;
-    if (cx > 0) marks[dir_index(g, cx - 1, cy, cz)] = 1;
+    for (int c = 0; c < 2; ++c)
+        for (int b = 0; b < 2; ++b)
+            for (int a = 0; a < 2; ++a)
+                if (cx - a >= 0 && cy - b >= 0 && cz - c >= 0)
+                    marks[dir_index(g, cx - a, cy - b, cz - c)] = 1;
 }
 
 __global__ void finish_dir_kernel(const int *__restrict__ marks, const int *__restrict__ ranks,
@@ -1707,7 +1712,8 @@ __device__ __forceinline__ unsigned lower_bound_key(const unsigned long long *ke
 // one thread per cell of every ranked block
 __global__ void fill_cells_kernel(GridDesc g, const unsigned long long *__restrict__ keys, int m,
                                   const int *__restrict__ block_of_rank, int nranked,
-                                  uint2 *__restrict__ run2, unsigned *__restrict__ end1)
+                                  uint2 *__restrict__ run2, unsigned *__restrict__ end1,
+                                  uint4 *__restrict__ quad)
 {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)nranked * 64) return;
@@ -1724,6 +1730,18 @@ __global__ void fill_cells_kernel(GridDesc g, const unsigned long long *__restri
     }
     run2[t] = make_uint2(s, e2);
     end1[t] = e1;
+    // the runs of the neighbours in y, in z and in both
+    uint2 nb[4] = { make_uint2(s, e2), make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u) };
+    for (int r = 1; r < 4; ++r) {
+        const int y = cy + (r & 1), z = cz + (r >> 1);
+        if (cx < g.nx && y < g.ny && z < g.nz) {
+            const unsigned long long key = ((unsigned long long)z * g.ny + y) * g.nx + cx;
+            nb[r].x = lower_bound_key(keys, m, key);
+            nb[r].y = lower_bound_key(keys, m, key + (cx + 1 < g.nx ? 2 : 1));
+        }
+    }
+    quad[2 * t] = make_uint4(nb[0].x, nb[0].y, nb[1].x, nb[1].y);
+    quad[2 * t + 1] = make_uint4(nb[2].x, nb[2].y, nb[3].x, nb[3].y);
 }
 
 __global__ void gather_target_kernel(const float *__restrict__ aos, const float *__restrict__ nrm_aos,
