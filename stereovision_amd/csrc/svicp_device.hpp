@@ -675,8 +675,10 @@ __device__ inline void solve_and_update(const SumsInFlight &sums, double *totals
     // the three angles' sines and cosines on three lanes at once
     double sn, cs;
     const double ang = t == 0 ? x[0] : t == 1 ? x[1] : x[2];
-    if (fabs(x[0]) <= 0.5 && fabs(x[1]) <= 0.5 && fabs(x[2]) <= 0.5) sincos_small(ang, sn, cs);
-    else sincos(ang, &sn, &cs);
+    if (__builtin_expect(fabs(x[0]) <= 0.5 && fabs(x[1]) <= 0.5 && fabs(x[2]) <= 0.5, 1))
+        sincos_small(ang, sn, cs);
+    else
+        sincos(ang, &sn, &cs);       // (long: kept out of the usual path)
     const double sx = lane_bcast(sn, 0), cx = lane_bcast(cs, 0), sy = lane_bcast(sn, 1),
                  cy = lane_bcast(cs, 1), sz = lane_bcast(sn, 2), cz = lane_bcast(cs, 2);
     // R = Rz(X2) * Ry(X1) * Rx(X0)
@@ -689,7 +691,7 @@ __device__ inline void solve_and_update(const SumsInFlight &sums, double *totals
         out_rt[9] = x[3]; out_rt[10] = x[4]; out_rt[11] = x[5];
     }
     SVICP_SOLVE_STAMP(14);
-    if (!record) return;
+    if (__builtin_expect(!record, 1)) return;
 
     // Trans = [R T; 0 1] * Trans, one element per lane
     double tnew = 0.0;
@@ -1136,7 +1138,9 @@ __device__ __forceinline__ void iterate_tile(
         const float4 e = queue[q];
         float best, second; int bpos, bidx;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (__builtin_expect(few, 1)) {     // the searching case tolerates being the far branch
+        // with the proof in use the searching case tolerates being the far branch (without
+        // it, it is the only case, and laid out as the far one it spills)
+        if (CERTIFY ? __builtin_expect(few, 1) : few) {
             const float4 f0 = found[q][0], f1 = found[q][1];
             t = f0; best = f0.w; second = f1.x; bpos = __float_as_int(f1.y);
         } else {
