@@ -417,6 +417,16 @@ def main():
                 "slowest_launch_ms": slowest_ms,
                 "frac_slowest_launch": bytes_fused / (slowest_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
+            # the standalone correspondence kernel (the reduction has no kernel of its own: it is
+            # fused into icp_iterate_kernel, whose roofline is the object above)
+            "roofline_correspondence": {
+                "bound": "hbm", "kernel": "nn1_kernel<false>", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "achieved": bytes_nn / (nn_capped_ms * 1e-3) / 1e9,
+                "frac": bytes_nn / (nn_capped_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "bytes_per_launch": bytes_nn, "launch_ms": nn_capped_ms,
+                "note": "20 B per query + 16 B per target point; the kernel is bound by its gather "
+                        "instructions (texture-address units), not by HBM",
+            },
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
             "kernels_ms": {"icp_iterate": fused_ms,
