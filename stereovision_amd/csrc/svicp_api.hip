@@ -1207,6 +1207,10 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
         hipLaunchKernelGGL(batch_reset_kernel, dim3(count), dim3(64), 0, ctx->stream, dp, iterations);
         LAUNCHCHK("batch_reset_kernel");
         for (int k = 0; k < iterations; ++k) {
+            if (k > 0) {
+                hipLaunchKernelGGL(batch_solve_kernel, dim3(count), dim3(64), 0, ctx->stream, dp, k - 1);
+                LAUNCHCHK("batch_solve_kernel");
+            }
             if (k == 0)
                 hipLaunchKernelGGL((icp_iterate_batch_kernel<false, false, 4>), dim3(total), dim3(kItThreads), 0, ctx->stream, dp, dm, k);
             else if (coherent)

@@ -842,13 +842,17 @@ __device__ __forceinline__ int choose_tile(const uint4 v, int nb, int b, bool &p
 // The work of one block: tile `tile` of a source of `nb` tiles.
 // INPLACE: the coordinates are updated where they are read (s?_in are not looked at); else
 // s?_in and s?_out may still be the same arrays (the batch decides per launch).
+// solve_now = false: a kernel launched before this one has solved the previous iteration's
+// system and left R, T in *st (the batch does that: one solve per pair instead of one per
+// block).
 template <bool APPLY, bool CERTIFY, int CH, bool INPLACE = false>
 __device__ __forceinline__ void iterate_tile(
     const GridDesc &g, const float *sx_in_, const float *sy_in_, const float *sz_in_,
     float *sx_out, float *sy_out, float *sz_out, int n, double *__restrict__ totals,
     double *__restrict__ deltas,
     IcpState *st, double *X_hist, double *info_hist, int iter, const CohParams &cp,
-    const PointState &ps, double *__restrict__ partials, const int fixed_tile, const int nb)
+    const PointState &ps, double *__restrict__ partials, const int fixed_tile, const int nb,
+    const bool solve_now = true)
 {
     constexpr int NP = kItPoints * kItHalves;         // points per thread
     __shared__ float4 queue[kItTile];                 // {x, y, z, index in tile}
@@ -867,7 +871,7 @@ __device__ __forceinline__ void iterate_tile(
 
     // ---- the wave that solves asks for the sums before any other load ----
     SumsInFlight sums;
-    if (APPLY && wv == 0)
+    if (APPLY && wv == 0 && solve_now)
         sums = request_sums(totals + (size_t)(iter - 1) * kNumSums,
                             deltas + (size_t)(iter - 1) * kDeltaRow);
     // ---- which tile: fixed_tile, or (fixed_tile < 0) block blockIdx.x's place in the
@@ -929,7 +933,10 @@ __device__ __forceinline__ void iterate_tile(
     float touched = 0.f;
     double R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1, T0 = 0, T1 = 0,
            T2 = 0;
-    if (APPLY) {
+    if (APPLY && !solve_now) {
+        R0 = st->R[0]; R1 = st->R[1]; R2 = st->R[2]; R3 = st->R[3]; R4 = st->R[4]; R5 = st->R[5];
+        R6 = st->R[6]; R7 = st->R[7]; R8 = st->R[8]; T0 = st->T[0]; T1 = st->T[1]; T2 = st->T[2];
+    } else if (APPLY) {
         // totals[k]: sums after iteration k - 1 (row 0 is zero); deltas[k]: changes made by iteration k
         if (wv == 0) {
             solve_and_update(sums, totals + (size_t)iter * kNumSums, st, X_hist, info_hist, iter - 1,
@@ -1220,7 +1227,8 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_batch_kernel(
     const bool first = iter <= 1;
     iterate_tile<APPLY, CERTIFY, CH>(g, first ? P->x0 : wx, first ? P->y0 : wy, first ? P->z0 : wz,
                                      wx, wy, wz, P->n, P->totals, P->deltas, P->st, P->X_hist,
-                                     P->info_hist, iter, cp, ps, P->partials, m.y, P->nb);
+                                     P->info_hist, iter, cp, ps, P->partials, m.y, P->nb,
+                                     /* solve_now = */ false);
 }
 
 // One block per pair: identity state, zero sums before iteration 0 and zero
@@ -1238,7 +1246,10 @@ __global__ __launch_bounds__(64) void batch_reset_kernel(const BatchPair *__rest
     for (int k = t; k < iters * kDeltaRow; k += 64) P->deltas[k] = 0.0;
 }
 
-// One wave per pair: the last iteration's solve.
+// One wave per pair: the solve of iteration `iter` (before the launch of iteration iter + 1,
+// and after the last one).  With a tile per block and 64 tiles per pair the blocks of an
+// iteration would otherwise solve every pair's system 64 times over, several rounds of
+// blocks deep, and a settled iteration would be little else.
 __global__ __launch_bounds__(64) void batch_solve_kernel(const BatchPair *__restrict__ pairs, int iter)
 {
     __shared__ double rt[12];
