@@ -106,7 +106,7 @@ struct svicp_ctx {
 struct svicp_batch {
     std::vector<svicp_ctx *> ctxs;
     svicp_ctx *lead = nullptr;          // device, stream and error text of the batch
-    DevBuf pairs, block_map, states;
+    DevBuf pairs, block_map, states, rt_all;   // rt_all: R, T of every pair for the next launch
     IcpState *h_states = nullptr;       // pinned
     int total_blocks = 0;
     int iters_cap = 0;
@@ -1137,7 +1137,7 @@ int svicp_batch_destroy(svicp_batch *b)
     (void)hipSetDevice(b->lead->device);
     (void)hipStreamSynchronize(b->lead->stream);
     if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
-    b->pairs.release(); b->block_map.release(); b->states.release();
+    b->pairs.release(); b->block_map.release(); b->states.release(); b->rt_all.release();
     if (b->h_states) (void)hipHostFree(b->h_states);
     delete b;
     return SVICP_OK;
@@ -1189,13 +1189,16 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
     HIPCHK(b->pairs.reserve(sizeof(BatchPair) * count));
     HIPCHK(b->block_map.reserve(sizeof(int2) * map.size()));
     HIPCHK(b->states.reserve(sizeof(IcpState) * count));
+    void *rb = b->rt_all.p;
+    HIPCHK(b->rt_all.reserve(sizeof(double) * 12 * count));
     if (!b->h_states) HIPCHK(hipHostMalloc((void **)&b->h_states, sizeof(IcpState) * count, 0));
     HIPCHK(hipMemcpyAsync(b->pairs.p, hp.data(), sizeof(BatchPair) * count, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(b->block_map.p, map.data(), sizeof(int2) * map.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));       // hp and map go out of scope
     const bool coherent = ctx->opt.coherent != 0;
     const int total = (int)map.size();
-    if (pb != b->pairs.p || mb != b->block_map.p || total != b->total_blocks || b->g_iters != iterations) {
+    if (pb != b->pairs.p || mb != b->block_map.p || rb != b->rt_all.p || total != b->total_blocks ||
+        b->g_iters != iterations) {
         if (b->gexec) { (void)hipGraphExecDestroy(b->gexec); b->gexec = nullptr; }
         b->g_iters = -1;
     }
@@ -1204,22 +1207,23 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
     auto enqueue = [&]() -> int {
         const BatchPair *dp = b->pairs.as<BatchPair>();
         const int2 *dm = b->block_map.as<int2>();
+        double *rt = b->rt_all.as<double>();
         hipLaunchKernelGGL(batch_reset_kernel, dim3(count), dim3(64), 0, ctx->stream, dp, iterations);
         LAUNCHCHK("batch_reset_kernel");
         for (int k = 0; k < iterations; ++k) {
             if (k > 0) {
-                hipLaunchKernelGGL(batch_solve_kernel, dim3(count), dim3(64), 0, ctx->stream, dp, k - 1);
+                hipLaunchKernelGGL(batch_solve_kernel, dim3(count), dim3(64), 0, ctx->stream, dp, k - 1, rt);
                 LAUNCHCHK("batch_solve_kernel");
             }
             if (k == 0)
-                hipLaunchKernelGGL((icp_iterate_batch_kernel<false, false, 4>), dim3(total), dim3(kItThreads), 0, ctx->stream, dp, dm, k);
+                hipLaunchKernelGGL((icp_iterate_batch_kernel<false, false, 4>), dim3(total), dim3(kItThreads), 0, ctx->stream, dp, dm, k, rt);
             else if (coherent)
-                hipLaunchKernelGGL((icp_iterate_batch_kernel<true, true, 4>), dim3(total), dim3(kItThreads), 0, ctx->stream, dp, dm, k);
+                hipLaunchKernelGGL((icp_iterate_batch_kernel<true, true, 4>), dim3(total), dim3(kItThreads), 0, ctx->stream, dp, dm, k, rt);
             else
-                hipLaunchKernelGGL((icp_iterate_batch_kernel<true, false, 4>), dim3(total), dim3(kItThreads), 0, ctx->stream, dp, dm, k);
+                hipLaunchKernelGGL((icp_iterate_batch_kernel<true, false, 4>), dim3(total), dim3(kItThreads), 0, ctx->stream, dp, dm, k, rt);
             LAUNCHCHK("icp_iterate_batch_kernel");
         }
-        hipLaunchKernelGGL(batch_solve_kernel, dim3(count), dim3(64), 0, ctx->stream, dp, iterations - 1);
+        hipLaunchKernelGGL(batch_solve_kernel, dim3(count), dim3(64), 0, ctx->stream, dp, iterations - 1, rt);
         LAUNCHCHK("batch_solve_kernel");
         const long long words = (long long)count * (sizeof(IcpState) / sizeof(double));
         hipLaunchKernelGGL(batch_collect_kernel, dim3(cdiv(words, 256)), dim3(256), 0, ctx->stream, dp, count, b->states.as<IcpState>());

@@ -843,8 +843,8 @@ __device__ __forceinline__ int choose_tile(const uint4 v, int nb, int b, bool &p
 // INPLACE: the coordinates are updated where they are read (s?_in are not looked at); else
 // s?_in and s?_out may still be the same arrays (the batch decides per launch).
 // solve_now = false: a kernel launched before this one has solved the previous iteration's
-// system and left R, T in *st (the batch does that: one solve per pair instead of one per
-// block).
+// system and left R (9) and T (3) at rt_given (the batch does that: one solve per pair instead
+// of one per block).
 template <bool APPLY, bool CERTIFY, int CH, bool INPLACE = false>
 __device__ __forceinline__ void iterate_tile(
     const GridDesc &g, const float *sx_in_, const float *sy_in_, const float *sz_in_,
@@ -852,7 +852,7 @@ __device__ __forceinline__ void iterate_tile(
     double *__restrict__ deltas,
     IcpState *st, double *X_hist, double *info_hist, int iter, const CohParams &cp,
     const PointState &ps, double *__restrict__ partials, const int fixed_tile, const int nb,
-    const bool solve_now = true)
+    const bool solve_now = true, const double *__restrict__ rt_given = nullptr)
 {
     constexpr int NP = kItPoints * kItHalves;         // points per thread
     __shared__ float4 queue[kItTile];                 // {x, y, z, index in tile}
@@ -934,8 +934,9 @@ __device__ __forceinline__ void iterate_tile(
     double R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1, T0 = 0, T1 = 0,
            T2 = 0;
     if (APPLY && !solve_now) {
-        R0 = st->R[0]; R1 = st->R[1]; R2 = st->R[2]; R3 = st->R[3]; R4 = st->R[4]; R5 = st->R[5];
-        R6 = st->R[6]; R7 = st->R[7]; R8 = st->R[8]; T0 = st->T[0]; T1 = st->T[1]; T2 = st->T[2];
+        R0 = rt_given[0]; R1 = rt_given[1]; R2 = rt_given[2]; R3 = rt_given[3]; R4 = rt_given[4];
+        R5 = rt_given[5]; R6 = rt_given[6]; R7 = rt_given[7]; R8 = rt_given[8]; T0 = rt_given[9];
+        T1 = rt_given[10]; T2 = rt_given[11];
     } else if (APPLY) {
         // totals[k]: sums after iteration k - 1 (row 0 is zero); deltas[k]: changes made by iteration k
         if (wv == 0) {
@@ -1213,8 +1214,11 @@ struct BatchPair {
 
 template <bool APPLY, bool CERTIFY, int CH>
 __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_batch_kernel(
-    const BatchPair *__restrict__ pairs, const int2 *__restrict__ block_map, int iter)
+    const BatchPair *__restrict__ pairs, const int2 *__restrict__ block_map, int iter,
+    const double *__restrict__ rt_all)
 {
+    // rt_all: R and T of every pair, 12 doubles each, indexed by the pair's number so that
+    // they can be asked for together with the pair's descriptor
     const int2 m = block_map[xcd_contiguous((int)blockIdx.x, (int)gridDim.x)];
     const BatchPair *P = pairs + m.x;
     const GridDesc g = P->g;
@@ -1228,7 +1232,7 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_batch_kernel(
     iterate_tile<APPLY, CERTIFY, CH>(g, first ? P->x0 : wx, first ? P->y0 : wy, first ? P->z0 : wz,
                                      wx, wy, wz, P->n, P->totals, P->deltas, P->st, P->X_hist,
                                      P->info_hist, iter, cp, ps, P->partials, m.y, P->nb,
-                                     /* solve_now = */ false);
+                                     /* solve_now = */ false, rt_all + 12 * (size_t)m.x);
 }
 
 // One block per pair: identity state, zero sums before iteration 0 and zero
@@ -1250,7 +1254,8 @@ __global__ __launch_bounds__(64) void batch_reset_kernel(const BatchPair *__rest
 // and after the last one).  With a tile per block and 64 tiles per pair the blocks of an
 // iteration would otherwise solve every pair's system 64 times over, several rounds of
 // blocks deep, and a settled iteration would be little else.
-__global__ __launch_bounds__(64) void batch_solve_kernel(const BatchPair *__restrict__ pairs, int iter)
+__global__ __launch_bounds__(64) void batch_solve_kernel(const BatchPair *__restrict__ pairs, int iter,
+                                                         double *__restrict__ rt_all)
 {
     __shared__ double rt[12];
     const BatchPair *P = pairs + blockIdx.x;
@@ -1259,6 +1264,7 @@ __global__ __launch_bounds__(64) void batch_solve_kernel(const BatchPair *__rest
                      P->totals + (size_t)(iter + 1) * kNumSums, P->st, P->X_hist, P->info_hist, iter,
                      true, rt);
     __syncthreads();
+    if (threadIdx.x < 12) rt_all[12 * (size_t)blockIdx.x + threadIdx.x] = rt[threadIdx.x];
     for (int k = threadIdx.x; k < kDeltaRow; k += 64) P->deltas[k] = 0.0;   // clean for the pair's next run
 }
 
