@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, time
 import stereovision_amd as sv
 from stereovision_amd import synth
