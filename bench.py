@@ -272,6 +272,15 @@ def main():
             "algorithmic_GBs": cal_bytes / (eval_ms * 1e-3) / 1e9,
             "scaling": "strong",
         }
+        if not distributed:
+            # the caller of the evaluation: one damped step of the refinement loop on the device
+            # (per-view blocks eliminated first), step and predicted decrease copied back
+            eng.ev.eval()
+            eng.ev.solve_damped(1e-3)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                eng.ev.solve_damped(1e-3)
+            calibration["damped_step_ms"] = (time.perf_counter() - t0) / 20 * 1e3
         if rank == 0 and world == 1 and args.cpu_iters > 0:
             from oracle import pyoracle as po
             t0 = time.perf_counter()

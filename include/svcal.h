@@ -69,6 +69,18 @@ int svcal_eval(svcal_ctx *ctx);
 /* Copies the results of the last svcal_eval into the caller's blocks. */
 int svcal_fetch(svcal_ctx *ctx, svcal_blocks *out);
 
+/* The damped step of the refinement loop from the blocks of the last svcal_eval, on the
+ * device: step = -(A + lam diag(A))^-1 G (CStereoCameraCalibration.cpp:288-291, where A is
+ * inverted densely), with the per-view 6 x 6 blocks eliminated first.  step_out: the
+ * parameter vector's length and order; predicted_out (may be NULL): step^T (lam step - G), the
+ * denominator of the gain ratio (:312-313).  SVICP_ERR_SINGULAR when a block is not positive
+ * definite.  Not for a context whose sums were replaced by svcal_shard_import (the views of
+ * the other ranks are not here). */
+int svcal_solve_damped(svcal_ctx *ctx, double lam, double *step_out, double *predicted_out);
+
+/* |e|^2 of the last svcal_eval alone (two doubles come back instead of every block). */
+int svcal_sq_residual(svcal_ctx *ctx, double *out);
+
 /* Runs the context's work on the caller's HIP stream (use_own = 0; NULL is the
  * default stream) or back on the context's own stream (use_own = 1). */
 int svcal_set_stream(svcal_ctx *ctx, void *hip_stream, int use_own);

@@ -33,6 +33,8 @@ CAL_SYMBOLS = {
     "svcal_set_params": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "svcal_eval": (C.c_int, [C.c_void_p]),
     "svcal_fetch": (C.c_int, [C.c_void_p, C.POINTER(_Blocks)]),
+    "svcal_sq_residual": (C.c_int, [C.c_void_p, _dp]),
+    "svcal_solve_damped": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp]),
     "svcal_time_eval": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "svcal_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "svcal_shard_export": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -125,6 +127,20 @@ class ReprojectionEvaluator:
         out["sq_residual"] = b.sq_residual
         return out
 
+    def sq_residual(self):
+        """|e|^2 of the last eval()."""
+        out = C.c_double(0.0)
+        self._check(self._lib.svcal_sq_residual(self._h, C.byref(out)))
+        return out.value
+
+    def solve_damped(self, lam):
+        """Device counterpart of solve_damped() below for the blocks of the last eval():
+        (step in the reference's parameter order, step^T (lam step - G))."""
+        step = np.empty(self.n_params(self.k), np.float64)
+        pred = C.c_double(0.0)
+        self._check(self._lib.svcal_solve_damped(self._h, C.c_double(lam), _d(step), C.byref(pred)))
+        return step, pred.value
+
     def evaluate(self, params, k=5, want_residual=True):
         self.set_params(params, k)
         self.eval()
@@ -215,13 +231,17 @@ def solve_damped(blocks, k, V, lam, stereo=True):
     return step, float(step @ (lam * step - G))
 
 
-def lm_refine(evaluator, params, k=5, max_iter=100, verbose=False, dense=False):
+def lm_refine(evaluator, params, k=5, max_iter=100, verbose=False, dense=False, host_solve=False):
     """The reference's damped Gauss-Newton loop (CStereoCameraCalibration.cpp:278-335):
     lambda0 = 1e-3, A + lambda diag(A), gain-ratio update, stops on |step| < 1e-5,
-    |e| < 1e-3 or 100 iterations.  One device evaluation per trial step; the linear solve
-    runs on the host, block-sparse (solve_damped) unless dense=True (small V only)."""
+    |e| < 1e-3 or 100 iterations.  One device evaluation per trial step.  The linear solve
+    runs on the device, block-sparse (svcal_solve_damped), and only the step and |e|^2 come
+    back; host_solve=True fetches the blocks and solves in numpy (solve_damped below, or
+    densely with dense=True, small V only)."""
     x = np.array(params, np.float64)
     V, stereo = evaluator.V, evaluator.stereo
+    if not (host_solve or dense) and hasattr(evaluator, "solve_damped"):
+        return _lm_refine_device(evaluator, x, k, max_iter, verbose)
 
     def solve(b, lam):
         if dense:
@@ -249,6 +269,38 @@ def lm_refine(evaluator, params, k=5, max_iter=100, verbose=False, dense=False):
             lam *= max(1.0 / 3.0, 1.0 - (2.0 * r - 1.0) ** 3)
             v = 2.0
         else:
+            lam *= v
+            v *= 2.0
+    return x, np.sqrt(err2)
+
+
+def _lm_refine_device(evaluator, x, k, max_iter, verbose):
+    """lm_refine with the blocks left on the device.  A rejected trial step costs one more
+    evaluation (the device holds the trial's blocks, the loop needs the old ones back)."""
+    def evaluate(p):
+        evaluator.set_params(p, k)
+        evaluator.eval()
+        return evaluator.sq_residual()
+
+    err2 = evaluate(x)
+    lam, v = 1.0e-3, 2.0
+    for it in range(max_iter):
+        step, denom = evaluator.solve_damped(lam)
+        if np.linalg.norm(step) < 1.0e-5:
+            break
+        new2 = evaluate(x + step)
+        r = (err2 - new2) / denom
+        if verbose:
+            print(f"iter {it}: |e| {np.sqrt(err2):.6g} -> {np.sqrt(new2):.6g}, gain {r:.3g}")
+        if r > 0:
+            x = x + step
+            err2 = new2
+            if np.sqrt(err2) < 1.0e-3:
+                break
+            lam *= max(1.0 / 3.0, 1.0 - (2.0 * r - 1.0) ** 3)
+            v = 2.0
+        else:
+            evaluate(x)
             lam *= v
             v *= 2.0
     return x, np.sqrt(err2)

@@ -23,6 +23,10 @@ struct svcal_ctx {
     double *world = nullptr, *left = nullptr, *right = nullptr, *params = nullptr;
     double *gram_view = nullptr, *gram_sum = nullptr, *residual = nullptr;
     size_t cap_params = 0;
+    // the damped solve: per-view solutions and contributions, shared step, whole step, flags
+    double *sv_W = nullptr, *sv_contrib = nullptr, *sv_dc = nullptr, *sv_step = nullptr, *sv_pred = nullptr;
+    int *sv_flags = nullptr;
+    int sv_views = 0;
 };
 
 namespace {
@@ -65,6 +69,11 @@ void free_obs(svcal_ctx *ctx)
     void *bufs[] = { ctx->world, ctx->left, ctx->right, ctx->gram_view, ctx->gram_sum, ctx->residual };
     for (void *b : bufs) if (b) (void)hipFree(b);
     ctx->world = ctx->left = ctx->right = ctx->gram_view = ctx->gram_sum = ctx->residual = nullptr;
+    void *sv[] = { ctx->sv_W, ctx->sv_contrib, ctx->sv_dc, ctx->sv_step, ctx->sv_pred, ctx->sv_flags };
+    for (void *b : sv) if (b) (void)hipFree(b);
+    ctx->sv_W = ctx->sv_contrib = ctx->sv_dc = ctx->sv_step = ctx->sv_pred = nullptr;
+    ctx->sv_flags = nullptr;
+    ctx->sv_views = 0;
 }
 
 int param_count(const svcal_ctx *ctx, int k)
@@ -235,6 +244,77 @@ int svcal_fetch(svcal_ctx *ctx, svcal_blocks *out)
         }
     }
     out->sq_residual = GL[at(15, 15)] + (ctx->stereo ? GR[at(15, 15)] : 0.0);
+    return SVICP_OK;
+}
+
+int svcal_sq_residual(svcal_ctx *ctx, double *out)
+{
+    if (!ctx || !out) return cfail(ctx, SVICP_ERR_ARG, "svcal_sq_residual: NULL argument");
+    if (!ctx->evaluated) return cfail(ctx, SVICP_ERR_ARG, "svcal_sq_residual: nothing evaluated yet");
+    CHK(hipSetDevice(ctx->device));
+    double e2[2] = { 0.0, 0.0 };                         // entry (15, 15) of each summed triangle
+    CHK(hipMemcpyAsync(&e2[0], ctx->gram_sum + kGram - 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->stereo)
+        CHK(hipMemcpyAsync(&e2[1], ctx->gram_sum + 2 * kGram - 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CHK(hipStreamSynchronize(ctx->stream));
+    *out = e2[0] + e2[1];
+    return SVICP_OK;
+}
+
+int svcal_solve_damped(svcal_ctx *ctx, double lam, double *step_out, double *predicted_out)
+{
+    if (!ctx || !step_out) return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_damped: NULL argument");
+    if (!ctx->evaluated) return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_damped: nothing evaluated yet");
+    if (!(lam >= 0.0) || !std::isfinite(lam))
+        return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_damped: the damping must be finite and >= 0");
+    CHK(hipSetDevice(ctx->device));
+    const int V = ctx->V, nI = 4 + ctx->k, P = param_count(ctx, ctx->k);
+    if (ctx->sv_views != V) {
+        void *sv[] = { ctx->sv_W, ctx->sv_contrib, ctx->sv_dc, ctx->sv_step, ctx->sv_pred, ctx->sv_flags };
+        for (void *b : sv) if (b) CHK(hipFree(b));
+        ctx->sv_W = ctx->sv_contrib = ctx->sv_dc = ctx->sv_step = ctx->sv_pred = nullptr;
+        ctx->sv_flags = nullptr;
+        ctx->sv_views = 0;
+        // sized for the longest parameter vector (five distortion terms, stereo)
+        CHK(hipMalloc((void **)&ctx->sv_W, sizeof(double) * (size_t)V * 6 * 10));
+        CHK(hipMalloc((void **)&ctx->sv_contrib, sizeof(double) * (size_t)V * 9 * 10));
+        CHK(hipMalloc((void **)&ctx->sv_dc, sizeof(double) * (kMaxShared + 1)));
+        CHK(hipMalloc((void **)&ctx->sv_step, sizeof(double) * (2 * 9 + 6 * (size_t)V + 6)));
+        CHK(hipMalloc((void **)&ctx->sv_pred, sizeof(double) * (size_t)V));
+        CHK(hipMalloc((void **)&ctx->sv_flags, sizeof(int)));
+        ctx->sv_views = V;
+    }
+    CHK(hipMemsetAsync(ctx->sv_flags, 0, sizeof(int), ctx->stream));
+    const int blocks = (V + 63) / 64;
+    hipLaunchKernelGGL(cal_view_eliminate_kernel, dim3(blocks), dim3(64), 0, ctx->stream, ctx->gram_view,
+                       V, nI, lam, ctx->sv_W, ctx->sv_contrib, ctx->sv_flags);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "cal_view_eliminate_kernel", e);
+    hipLaunchKernelGGL(cal_shared_solve_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->gram_sum,
+                       ctx->sv_contrib, V, nI, ctx->stereo, lam, ctx->sv_dc, ctx->sv_flags);
+    e = hipGetLastError();
+    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "cal_shared_solve_kernel", e);
+    hipLaunchKernelGGL(cal_view_step_kernel, dim3(blocks), dim3(64), 0, ctx->stream, ctx->gram_view,
+                       ctx->sv_W, ctx->sv_dc, V, nI, ctx->stereo, lam, ctx->sv_step, ctx->sv_pred);
+    e = hipGetLastError();
+    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "cal_view_step_kernel", e);
+    std::vector<double> pv(V);
+    double shared_pred = 0.0;
+    int flags = 0;
+    CHK(hipMemcpyAsync(step_out, ctx->sv_step, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+    CHK(hipMemcpyAsync(pv.data(), ctx->sv_pred, sizeof(double) * V, hipMemcpyDeviceToHost, ctx->stream));
+    CHK(hipMemcpyAsync(&shared_pred, ctx->sv_dc + kMaxShared, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CHK(hipMemcpyAsync(&flags, ctx->sv_flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CHK(hipStreamSynchronize(ctx->stream));
+    if (flags)
+        return cfail(ctx, SVICP_ERR_SINGULAR,
+                     flags & 2 ? "svcal_solve_damped: the shared system is not positive definite"
+                               : "svcal_solve_damped: a view's 6 x 6 block is not positive definite");
+    if (predicted_out) {
+        double s = shared_pred;
+        for (int v = 0; v < V; ++v) s += pv[v];          // in view order, always
+        *predicted_out = s;
+    }
     return SVICP_OK;
 }
 

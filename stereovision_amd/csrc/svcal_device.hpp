@@ -302,4 +302,196 @@ __global__ __launch_bounds__(256) void rectify_maps_kernel(RectifyCam L, Rectify
     xr[p] = a; yr[p] = b;
 }
 
+// ------------------------------------------------------------------------
+// The damped step of the refinement loop on the device:
+//     step = -(A + lam diag(A))^-1 G                (CStereoCameraCalibration.cpp:288-291)
+// without forming A.  The per-view 6 x 6 blocks (EE) couple only with the left camera's
+// intrinsics (LE: the reference fills a view's extrinsic columns in the left image's rows
+// only), so they are eliminated first, view by view (cal_view_eliminate_kernel), which
+// leaves a system in the shared parameters (cal_shared_solve_kernel: 2 nI + 6 of them, nI
+// monocular), and the views' steps follow from the shared one (cal_view_step_kernel).
+// The reference inverts the dense matrix (12 024 x 12 024 at 2000 views).
+// ------------------------------------------------------------------------
+constexpr int kMaxShared = 24;      // 2 * (4 + 5) + 6
+
+// entry (a, b) of a 16 x 16 upper triangle stored row by row
+__device__ __forceinline__ int tri_at(int a, int b)
+{
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    return lo * 16 - (lo * (lo - 1)) / 2 + (hi - lo);
+}
+
+// One thread per view.  W[v] = (EE + lam diag EE)^-1 [LE^T | gE]   (6 x (nI + 1), kept for the
+// last kernel) and contrib[v] = LE W[v]   (nI x (nI + 1): what the view takes out of the shared
+// system).  flags[0] is set when a block is not positive definite.
+__global__ void cal_view_eliminate_kernel(const double *__restrict__ gram_view, int V, int nI,
+                                          double lam, double *__restrict__ W,
+                                          double *__restrict__ contrib, int *__restrict__ flags)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const double *G = gram_view + (size_t)v * 2 * kGram;       // the left camera's triangle
+    double L[6][6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int p = 0; p <= q; ++p) L[q][p] = G[tri_at(nI + q, nI + p)] * (q == p ? 1.0 + lam : 1.0);
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {                              // Cholesky, lower factor in place
+        double d = L[c][c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) d -= L[c][k] * L[c][k];
+        if (!(d > 0.0)) { ok = false; d = 1.0; }
+        const double r = 1.0 / sqrt(d);
+        L[c][c] = r;                                           // the reciprocal of the diagonal
+#pragma unroll
+        for (int q = c + 1; q < 6; ++q) {
+            double s = L[q][c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) s -= L[q][k] * L[c][k];
+            L[q][c] = s * r;
+        }
+    }
+    if (!ok) atomicOr(flags, 1);
+    const int nc = nI + 1;
+    for (int c = 0; c < nc; ++c) {                             // column c of [LE^T | gE]
+        double x[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) x[q] = G[tri_at(c < nI ? c : nI + q, c < nI ? nI + q : 15)];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {                          // L y = b
+            double s = x[q];
+#pragma unroll
+            for (int k = 0; k < q; ++k) s -= L[q][k] * x[k];
+            x[q] = s * L[q][q];
+        }
+#pragma unroll
+        for (int q = 5; q >= 0; --q) {                         // L^T w = y
+            double s = x[q];
+#pragma unroll
+            for (int k = q + 1; k < 6; ++k) s -= L[k][q] * x[k];
+            x[q] = s * L[q][q];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) W[((size_t)v * 6 + q) * nc + c] = x[q];
+        for (int a = 0; a < nI; ++a) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) s += G[tri_at(a, nI + q)] * x[q];
+            contrib[(size_t)v * nI * nc + a * nc + c] = s;
+        }
+    }
+}
+
+// One block.  Sums the views' contributions in a fixed order, assembles the damped shared
+// system from the summed triangles, solves it (Cholesky in LDS) and writes the shared part
+// of the step: dc[0 .. nC), followed by dc^T (lam dc - gc) in dc[kMaxShared].
+__global__ __launch_bounds__(256) void cal_shared_solve_kernel(
+    const double *__restrict__ gram_sum, const double *__restrict__ contrib, int V, int nI,
+    int stereo, double lam, double *__restrict__ dc_out, int *__restrict__ flags)
+{
+    __shared__ double S[kMaxShared][kMaxShared + 1];           // last column: the gradient
+    __shared__ double part[256];
+    __shared__ double csum[9 * 10];
+    const int nc = nI + 1, ne = nI * nc, nC = stereo ? 2 * nI + 6 : nI;
+    const int t = threadIdx.x;
+    // ---- sum over the views: entry e by threads e and e + 128, half of the views each ----
+    {
+        const int e = t & 127, half = t >> 7;
+        double s = 0.0;
+        if (e < ne) {
+            const int v0 = half ? V / 2 : 0, v1 = half ? V : V / 2;
+            for (int v = v0; v < v1; ++v) s += contrib[(size_t)v * ne + e];
+        }
+        part[t] = s;
+    }
+    __syncthreads();
+    if (t < ne) csum[t] = part[t] + part[t + 128];
+    for (int i = t; i < kMaxShared * (kMaxShared + 1); i += 256) (&S[0][0])[i] = 0.0;
+    __syncthreads();
+    // ---- the shared system ----
+    const double *GL = gram_sum, *GR = gram_sum + kGram;
+    for (int i = t; i < nC * nC; i += 256) {
+        const int r = i / nC, c = i % nC;
+        double a = 0.0;
+        if (r < nI && c < nI) a = GL[tri_at(r, c)] - csum[r * nc + c];
+        else if (stereo && r >= nI && c >= nI) {
+            const int rr = r - nI, cc = c - nI;                // right intrinsics, then the pose
+            a = GR[tri_at(rr, cc)];                            // (RR, RS, SS sit where u has them)
+        }
+        S[r][c] = r == c ? a + lam * (r < nI ? GL[tri_at(r, r)] : GR[tri_at(r - nI, r - nI)]) : a;
+    }
+    for (int r = t; r < nC; r += 256)
+        S[r][kMaxShared] = r < nI ? GL[tri_at(r, 15)] - csum[r * nc + nI] : GR[tri_at(r - nI, 15)];
+    __syncthreads();
+    // ---- Cholesky, column by column; thread r owns row r ----
+    for (int c = 0; c < nC; ++c) {
+        if (t == c) {
+            double d = S[c][c];
+            for (int k = 0; k < c; ++k) d -= S[c][k] * S[c][k];
+            if (!(d > 0.0)) { atomicOr(flags, 2); d = 1.0; }
+            S[c][c] = sqrt(d);
+        }
+        __syncthreads();
+        if (t > c && t < nC) {
+            double s = S[t][c];
+            for (int k = 0; k < c; ++k) s -= S[t][k] * S[c][k];
+            S[t][c] = s / S[c][c];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        double x[kMaxShared];
+        for (int r = 0; r < nC; ++r) {
+            double s = S[r][kMaxShared];
+            for (int k = 0; k < r; ++k) s -= S[r][k] * x[k];
+            x[r] = s / S[r][r];
+        }
+        for (int r = nC - 1; r >= 0; --r) {
+            double s = x[r];
+            for (int k = r + 1; k < nC; ++k) s -= S[k][r] * x[k];
+            x[r] = s / S[r][r];
+        }
+        // the gradient of the shared parameters as the caller knows it (before elimination)
+        double pred = 0.0;
+        for (int r = 0; r < nC; ++r) {
+            const double g = r < nI ? GL[tri_at(r, 15)] : GR[tri_at(r - nI, 15)];
+            const double d = -x[r];
+            dc_out[r] = d;
+            pred += d * (lam * d - g);
+        }
+        dc_out[kMaxShared] = pred;
+    }
+}
+
+// One thread per view: de = -(W[:, nI] + W[:, :nI] dc[:nI]) into the step vector (the
+// reference's parameter order: shared intrinsics, the views' six each, then the stereo
+// pose), and the view's share of step^T (lam step - G) into pred_view[v].
+__global__ void cal_view_step_kernel(const double *__restrict__ gram_view, const double *__restrict__ W,
+                                     const double *__restrict__ dc, int V, int nI, int stereo,
+                                     double lam, double *__restrict__ step,
+                                     double *__restrict__ pred_view)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nc = nI + 1, head = stereo ? 2 * nI : nI;
+    if (v == 0) {
+        for (int r = 0; r < head; ++r) step[r] = dc[r];
+        if (stereo) for (int q = 0; q < 6; ++q) step[head + 6 * (size_t)V + q] = dc[2 * nI + q];
+    }
+    if (v >= V) return;
+    const double *G = gram_view + (size_t)v * 2 * kGram;
+    double pred = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const double *w = W + ((size_t)v * 6 + q) * nc;
+        double s = w[nI];
+        for (int a = 0; a < nI; ++a) s += w[a] * dc[a];
+        const double d = -s;
+        step[head + 6 * (size_t)v + q] = d;
+        pred += d * (lam * d - G[tri_at(nI + q, 15)]);
+    }
+    pred_view[v] = pred;
+}
+
 }  // namespace svcal

@@ -149,11 +149,58 @@ def test_two_thousand_views_refine_to_the_noise_floor(po):
     assert np.abs(x[-3:] - truth[-3:]).max() < 0.05         # baseline, millimetres
 
 
+@pytest.mark.parametrize("views,stereo,k", [(6, True, 5), (6, True, 2), (7, False, 5), (2000, True, 5)])
+def test_device_step_equals_host_step(views, stereo, k):
+    """svcal_solve_damped against the numpy block-sparse solve of the fetched blocks (and,
+    for the small problems, against the dense solve the reference performs): the same step
+    and the same predicted decrease to rounding, for several dampings."""
+    from stereovision_amd.calib import ReprojectionEvaluator, assemble_dense, solve_damped
+    w, l, r, _, start = synth.make_stereo_views(views=views, perturb=1e-2)
+    if not stereo:
+        nI = 9
+        start = np.concatenate([start[:nI], start[2 * nI: 2 * nI + 6 * views]])
+    elif k == 2:
+        start = np.concatenate([start[:6], start[9:15], start[18:]])
+    ev = ReprojectionEvaluator(w, l, r if stereo else None)
+    b = ev.evaluate(start, k, want_residual=False)
+    assert ev.sq_residual() == b["sq_residual"]
+    for lam in (0.0, 1e-3, 0.7):
+        step, pred = ev.solve_damped(lam)
+        want, wpred = solve_damped(b, k, views, lam, stereo)
+        scale = np.abs(want).max()
+        assert np.abs(step - want).max() < 1e-8 * scale
+        assert pred == pytest.approx(wpred, rel=1e-8)
+        if views < 100:
+            A, G = assemble_dense(b, k, views, stereo)
+            dense = -np.linalg.solve(A + lam * np.diag(np.diag(A)), G)
+            assert np.abs(step - dense).max() < 1e-6 * scale
+    ev.close()
+
+
+def test_device_step_argument_errors():
+    from stereovision_amd import SvicpError
+    from stereovision_amd.calib import ReprojectionEvaluator
+    w, l, r, _, start = synth.make_stereo_views(views=4)
+    ev = ReprojectionEvaluator(w, l, r)
+    with pytest.raises(SvicpError):
+        ev.solve_damped(1e-3)                   # nothing evaluated yet
+    with pytest.raises(SvicpError):
+        ev.sq_residual()
+    ev.evaluate(start, 5, want_residual=False)
+    with pytest.raises(SvicpError):
+        ev.solve_damped(-1.0)
+    with pytest.raises(SvicpError):
+        ev.solve_damped(float("nan"))
+    ev.close()
+
+
 def test_dense_and_block_sparse_loops_agree(po):
     from stereovision_amd.calib import ReprojectionEvaluator, lm_refine
     w, l, r, _, start = synth.make_stereo_views(views=6)
     ev = ReprojectionEvaluator(w, l, r)
     xa, ea = lm_refine(ev, start, 5, max_iter=15, dense=True)
+    xh, eh = lm_refine(ev, start, 5, max_iter=15, host_solve=True)
+    assert ea == pytest.approx(eh, rel=1e-6)
     xb, eb = lm_refine(ev, start, 5, max_iter=15, dense=False)
     # the two solves differ in rounding only, but the system is ill conditioned (k3 is barely
     # observable), so the iterates drift apart in the eighth digit of the error
