@@ -216,7 +216,7 @@ def main():
         batch.run(args.iters)
         barrier()
         t0 = time.perf_counter()
-        reps = 5
+        reps = 20
         for _ in range(reps):
             batch.run(args.iters)
         barrier()
