@@ -189,19 +189,36 @@ int sort_pairs(svicp_ctx *ctx, int64_t count, int bits)
     return SVICP_OK;
 }
 
-// exact k-NN of n device-resident AoS queries; results to device idx/d2 (n x k)
+// exact k-NN of n device-resident AoS queries; results to device idx/d2 (n x k).
+// k <= kKnnWaveK: a wave per query; the few queries it passes on (too many candidates at one
+// distance) go on a list to the thread-per-query search, and what no ring settles to the
+// exhaustive pass.  Larger k: the thread-per-query search for every query.
 int run_knn(svicp_ctx *ctx, const float *q_aos, int64_t n, int k, int *idx, float *d2)
 {
     if (n == 0) return SVICP_OK;
-    HIPCHK(ctx->unresolved.reserve(sizeof(int) * n));
-    HIPCHK(ctx->n_unres.reserve(sizeof(int)));
-    HIPCHK(hipMemsetAsync(ctx->n_unres.p, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx->unresolved.reserve(sizeof(int) * 2 * n));
+    HIPCHK(ctx->n_unres.reserve(sizeof(int) * 2));
+    HIPCHK(hipMemsetAsync(ctx->n_unres.p, 0, sizeof(int) * 2, ctx->stream));
     const int grid = std::min(cdiv(n, kBlockThreads), 65536);
-    int *unres = ctx->unresolved.as<int>(), *nun = ctx->n_unres.as<int>();
+    int *list = ctx->unresolved.as<int>(), *nlist = ctx->n_unres.as<int>();
+    int *unres = list + n, *nun = nlist + 1;
+    const bool by_wave = k <= kKnnWaveK;
+    if (by_wave) {
+        const int waves = kBlockThreads / 64;
+        hipLaunchKernelGGL(knn_wave_kernel, dim3(std::min(cdiv(n, waves), 8192)), dim3(kBlockThreads), 0,
+                           ctx->stream, ctx->g, q_aos, (int)n, k, idx, d2, list, nlist, unres, nun);
+        LAUNCHCHK("knn_wave_kernel");
+    }
 #define KNN_LAUNCH(KM)                                                                           \
     do {                                                                                         \
-        hipLaunchKernelGGL((knn_kernel<KM, false>), dim3(grid), dim3(kBlockThreads), 0,          \
-                           ctx->stream, ctx->g, q_aos, (int)n, k, idx, d2, unres, nun);          \
+        if (by_wave)                                                                             \
+            hipLaunchKernelGGL((knn_kernel<KM, true>), dim3(std::min(grid, 1024)),               \
+                               dim3(kBlockThreads), 0, ctx->stream, ctx->g, q_aos, (int)n, k,    \
+                               idx, d2, list, nlist, unres, nun);                                \
+        else                                                                                     \
+            hipLaunchKernelGGL((knn_kernel<KM, false>), dim3(grid), dim3(kBlockThreads), 0,      \
+                               ctx->stream, ctx->g, q_aos, (int)n, k, idx, d2, nullptr, nullptr, \
+                               unres, nun);                                                      \
         LAUNCHCHK("knn_kernel");                                                                 \
         hipLaunchKernelGGL((knn_brute_block_kernel<KM>), dim3(2048), dim3(kBlockThreads), 0,     \
                            ctx->stream, ctx->g, q_aos, k, idx, d2, unres, nun);                  \

@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_brute_kernel(
 // ------------------------------------------------------------------------
 // Exact k-NN, 1 <= k <= KMAX (CKNNSearch::getKNeighbour, CKNNSearch.cpp:67-71).
 // One thread per query keeps the k best (distance, index) pairs sorted in
-// private memory.  BRUTE = true scans the whole target for the queued queries.
+// private memory (indexed by a variable, so it lives in scratch: the slow, general path).
 // ------------------------------------------------------------------------
 template <int KMAX>
 struct KList {
@@ -1473,40 +1473,35 @@ struct KList {
     }
 };
 
-template <int KMAX, bool BRUTE>
+template <int KMAX, bool LIST>
 __global__ __launch_bounds__(kBlockThreads) void knn_kernel(
     GridDesc g, const float *__restrict__ q_aos, int n, int k, int *__restrict__ idx_out,
-    float *__restrict__ d2_out, int *__restrict__ unresolved, int *__restrict__ n_unresolved)
+    float *__restrict__ d2_out, const int *__restrict__ list, const int *__restrict__ n_list,
+    int *__restrict__ unresolved, int *__restrict__ n_unresolved)
 {
-    const int total = BRUTE ? *n_unresolved : n;
+    // LIST: the queries named in `list` (those the wave search below passed on)
+    const int total = LIST ? *n_list : n;
+    const int first = k > 1 ? 1 : 0;
     for (long long t = (long long)blockIdx.x * kBlockThreads + threadIdx.x; t < total;
          t += (long long)gridDim.x * kBlockThreads) {
-        const long long i = BRUTE ? unresolved[t] : t;
+        const long long i = LIST ? list[t] : t;
         float qx = q_aos[3 * i], qy = q_aos[3 * i + 1], qz = q_aos[3 * i + 2];
         KList<KMAX> L;
         L.clear(k);
         bool done = false;
-        if (BRUTE) {
-            for (int j = 0; j < g.m; ++j) {
+        int cx, cy, cz;
+        clamped_origin(g, qx, qy, qz, cx, cy, cz);
+        for (int ring = first; ring <= kKnnMaxRing; ++ring) {
+            int x0, x1, y0, y1, z0, z1;
+            float rho = ring_box(g, qx, qy, qz, cx, cy, cz, ring, x0, x1, y0, y1, z0, z1);
+            L.clear(k);
+            scan_box(g, x0, x1, y0, y1, z0, z1, [&](unsigned j) {
                 float4 p = g.pts[j];
                 L.insert(dist2(qx, qy, qz, p), __float_as_int(p.w));
-            }
-            done = true;
-        } else {
-            int cx, cy, cz;
-            clamped_origin(g, qx, qy, qz, cx, cy, cz);
-            for (int ring = (k > 1 ? 1 : 0); ring <= kKnnMaxRing; ++ring) {
-                int x0, x1, y0, y1, z0, z1;
-                float rho = ring_box(g, qx, qy, qz, cx, cy, cz, ring, x0, x1, y0, y1, z0, z1);
-                L.clear(k);
-                scan_box(g, x0, x1, y0, y1, z0, z1, [&](unsigned j) {
-                    float4 p = g.pts[j];
-                    L.insert(dist2(qx, qy, qz, p), __float_as_int(p.w));
-                });
-                if (rho == INFINITY || (L.cnt == k && rho > 0.f && L.d[k - 1] <= rho * rho)) {
-                    done = true;
-                    break;
-                }
+            });
+            if (rho == INFINITY || (L.cnt == k && rho > 0.f && L.d[k - 1] <= rho * rho)) {
+                done = true;
+                break;
             }
         }
         if (done) {
@@ -1519,6 +1514,219 @@ __global__ __launch_bounds__(kBlockThreads) void knn_kernel(
             unresolved[slot] = (int)i;
         }
     }
+}
+
+// ------------------------------------------------------------------------
+// Exact k-NN, k <= kKnnWaveK, by one whole wave per query (the same answers as
+// knn_kernel: the k smallest (distance, index) keys of a ring's cell box, accepted
+// when the k-th lies within the radius the box is certain to cover, else the next ring).
+//
+// A box is rows of cells along x, each row at most one contiguous run of the sorted
+// target per block of cells it crosses.  64 runs at a time, one per lane: a prefix sum
+// over the run lengths numbers the candidates, and the candidates are dealt to the
+// lanes 64 at a time (run heads marked in LDS, spread by a prefix maximum), so the
+// loads are contiguous and no lane idles on a short run.  Candidates are taken in
+// rounds of kKnnWaveChunks x 64; after each round the wave keeps the at most 64
+// smallest keys, one per lane: a bisection on the distance bits finds a bound t with
+// k <= #(distance <= t) <= 64 (counting is a ballot and a population count), the keys
+// within t are packed through LDS, and at the end every kept key counts the kept keys
+// below it, which is its place in the answer.  More than 64 - k + 1 candidates at one
+// distance defeat the bisection: such a query goes on `ties` for knn_kernel<., true>;
+// one that the last ring does not settle goes on `far` for the exhaustive pass.  The
+// lists are appended to 64 entries at a time (one atomic per 64: same-address atomics
+// serialise, and every query of a cloud far from the target ends on a list).
+// ------------------------------------------------------------------------
+constexpr int kKnnWaveK = 32;
+constexpr int kKnnWaveChunks = 8;
+constexpr int kKnnWaveRound = 64 * kKnnWaveChunks;
+
+__device__ __forceinline__ int wave_inclusive_max(int v)   // v >= 0 in every lane
+{
+    v = max(v, dpp_get<0x111, 0xf, true>(v));
+    v = max(v, dpp_get<0x112, 0xf, true>(v));
+    v = max(v, dpp_get<0x114, 0xf, true>(v));
+    v = max(v, dpp_get<0x118, 0xf, true>(v));
+    v = max(v, dpp_get<0x142, 0xa, false>(v));
+    v = max(v, dpp_get<0x143, 0xc, false>(v));
+    return v;
+}
+
+// A wave's share of a list that many waves append to: lane j holds the j-th pending entry.
+struct WaveAppender {
+    int pending, count;
+    __device__ void flush(int *list, int *n_list)
+    {
+        if (count == 0) return;
+        int slot = 0;
+        if ((threadIdx.x & 63) == 0) slot = atomicAdd(n_list, count);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if ((int)(threadIdx.x & 63) < count) list[slot + (threadIdx.x & 63)] = pending;
+        count = 0;
+    }
+    __device__ void add(int v, int *list, int *n_list)   // v the same in every lane
+    {
+        if ((int)(threadIdx.x & 63) == count) pending = v;
+        if (++count == 64) flush(list, n_list);
+    }
+};
+
+__global__ __launch_bounds__(kBlockThreads) void knn_wave_kernel(
+    GridDesc g, const float *__restrict__ q_aos, int n, int k, int *__restrict__ idx_out,
+    float *__restrict__ d2_out, int *__restrict__ ties, int *__restrict__ n_ties,
+    int *__restrict__ far, int *__restrict__ n_far)
+{
+    constexpr int W = kBlockThreads / 64;
+    constexpr unsigned long long kNone = ~0ull;          // sorts after every real key
+    constexpr unsigned kNanBits = 0x7fc00000u;           // every real distance's bits are <= this
+    __shared__ int head[W][kKnnWaveRound];
+    __shared__ unsigned long long picked[W][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int *const my_head = head[wv];
+    unsigned long long *const my_picked = picked[wv];
+    WaveAppender to_ties = { 0, 0 }, to_far = { 0, 0 };
+
+    for (long long i = (long long)blockIdx.x * W + wv; i < n; i += (long long)gridDim.x * W) {
+        const float qx = q_aos[3 * i], qy = q_aos[3 * i + 1], qz = q_aos[3 * i + 2];
+        int cx, cy, cz;
+        clamped_origin(g, qx, qy, qz, cx, cy, cz);
+        bool done = false, gave_up = false;
+        unsigned long long best = kNone;     // the kept keys, one per lane, in no order
+        int kept = 0, place = 0;
+
+        for (int ring = (k > 1 ? 1 : 0); ring <= kKnnMaxRing && !done && !gave_up; ++ring) {
+            int x0, x1, y0, y1, z0, z1;
+            const float rho = ring_box(g, qx, qy, qz, cx, cy, cz, ring, x0, x1, y0, y1, z0, z1);
+            const int bx0 = x0 >> 2, nbxs = (x1 >> 2) - bx0 + 1, ny = y1 - y0 + 1;
+            const int nseg = nbxs * ny * (z1 - z0 + 1);
+            best = kNone;
+            kept = 0;
+            for (int sg = 0; sg < nseg && !gave_up; sg += 64) {
+                // this lane's run: segment (z, y, block in x)
+                unsigned s = 0;
+                int len = 0;
+                if (sg + lane < nseg) {
+                    const int row = (sg + lane) / nbxs, bx = bx0 + (sg + lane) - row * nbxs;
+                    const int zr = row / ny, y = y0 + row - zr * ny, z = z0 + zr;
+                    const int rank = g.dir[((z >> 2) * g.nby + (y >> 2)) * g.nbx + bx];
+                    if (rank >= 0) {
+                        const int xa = max(x0, bx * 4), xb = min(x1, bx * 4 + 3);
+                        const int base = rank * 64 + (((z & 3) << 4) | ((y & 3) << 2));
+                        s = g.run2[base + (xa & 3)].x;
+                        len = (int)(g.end1[base + (xb & 3)] - s);
+                    }
+                }
+                const int incl = wave_inclusive_scan(len), excl = incl - len;
+                const int T = __builtin_amdgcn_readlane(incl, 63);
+
+                for (int base = 0; base < T; base += kKnnWaveRound) {
+                    const int here = min(T - base, kKnnWaveRound);
+                    // run heads of this round; the run under way at `base` heads position 0
+                    wave_lds_sync();
+#pragma unroll
+                    for (int c = 0; c < kKnnWaveChunks; ++c)
+                        if (c * 64 < here) my_head[c * 64 + lane] = 0;
+                    wave_lds_sync();
+                    if (len > 0 && incl > base && excl < base + kKnnWaveRound)
+                        my_head[max(excl - base, 0)] = lane + 1;
+                    wave_lds_sync();
+
+                    unsigned long long key[kKnnWaveChunks];
+                    int run_before = 0;
+#pragma unroll
+                    for (int c = 0; c < kKnnWaveChunks; ++c) {
+                        key[c] = kNone;
+                        if (c * 64 < here) {
+                            const int p = c * 64 + lane;
+                            const int h = max(wave_inclusive_max(my_head[p]), run_before);
+                            run_before = __builtin_amdgcn_readlane(h, 63);
+                            const int seg = max(h - 1, 0);
+                            const unsigned s_seg = (unsigned)__shfl((int)s, seg, 64);
+                            const int excl_seg = __shfl(excl, seg, 64);
+                            if (p < here) {
+                                const float4 pt = g.pts[s_seg + (unsigned)(base + p - excl_seg)];
+                                const float d = dist2(qx, qy, qz, pt);
+                                const unsigned bits = d == d ? __float_as_uint(d) : kNanBits;
+                                key[c] = ((unsigned long long)bits << 32) | __float_as_uint(pt.w);
+                            }
+                        }
+                    }
+
+                    // bound t: k <= #(distance bits <= t) <= 64 over this round and the kept keys
+                    auto count_within = [&](unsigned t) {
+                        int cnt = __popcll(__ballot((unsigned)(best >> 32) <= t));
+#pragma unroll
+                        for (int c = 0; c < kKnnWaveChunks; ++c)
+                            if (c * 64 < here) cnt += __popcll(__ballot((unsigned)(key[c] >> 32) <= t));
+                        return cnt;
+                    };
+                    unsigned t = kNanBits;
+                    if (here + kept > 64) {
+                        long long lo = -1, hi = kNanBits;      // #(<= lo) < k, #(<= hi) > 64
+                        for (;;) {
+                            if (hi - lo < 2) { gave_up = true; break; }
+                            const long long mid = (lo + hi) >> 1;
+                            const int cnt = count_within((unsigned)mid);
+                            if (cnt < k) lo = mid;
+                            else if (cnt > 64) hi = mid;
+                            else { t = (unsigned)mid; break; }
+                        }
+                        if (gave_up) break;
+                    }
+                    // pack the keys within t: one per lane
+                    int pos = 0;
+                    auto pack = [&](unsigned long long v) {
+                        const bool in = (unsigned)(v >> 32) <= t;
+                        const unsigned long long m = __ballot(in);
+                        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                        if (in) my_picked[pos + before] = v;
+                        pos += __popcll(m);
+                    };
+                    pack(best);
+#pragma unroll
+                    for (int c = 0; c < kKnnWaveChunks; ++c)
+                        if (c * 64 < here) pack(key[c]);
+                    wave_lds_sync();
+                    kept = pos;
+                    best = lane < kept ? my_picked[lane] : kNone;
+                }
+            }
+            if (gave_up) break;
+            // place of each kept key among the kept keys (distinct: the index is part of a key)
+            place = 0;
+            for (int j = 0; j < kept; ++j) {
+                const unsigned lo = __builtin_amdgcn_readlane((unsigned)best, j);
+                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(best >> 32), j);
+                place += (((unsigned long long)hi << 32) | lo) < best ? 1 : 0;
+            }
+            if (rho == INFINITY) {
+                done = true;
+            } else if (kept >= k && rho > 0.f) {
+                const unsigned long long m = __ballot(lane < kept && place == k - 1);
+                const int who = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                const float dk = __uint_as_float(__builtin_amdgcn_readlane((unsigned)(best >> 32), who));
+                done = dk <= rho * rho;
+            }
+        }
+        if (done) {
+            const int have = min(kept, k);
+            if (lane < kept && place < k) {
+                idx_out[i * k + place] = (int)(unsigned)best;
+                d2_out[i * k + place] = __uint_as_float((unsigned)(best >> 32));
+            }
+            if (lane < k - have) {
+                idx_out[i * k + have + lane] = -1;
+                d2_out[i * k + have + lane] = INFINITY;
+            }
+        } else if (gave_up) {
+            to_ties.add((int)i, ties, n_ties);
+        } else {
+            to_far.add((int)i, far, n_far);
+        }
+    }
+    to_ties.flush(ties, n_ties);
+    to_far.flush(far, n_far);
 }
 
 // Exhaustive pass of the k-NN for the queries the ring search could not settle: one

@@ -233,6 +233,26 @@ def test_duplicates_and_k_larger_than_target(ctx):
     assert np.isinf(d2[0, 4:]).all() and d2[0, 0] == d2[0, 1]
 
 
+def test_knn_dense_sparse_and_coincident_targets(ctx, po):
+    """The wave-per-query search: a cell box with far more candidates than one round
+    takes (several rounds, each keeping the best), boxes with fewer than k points (wider
+    rings), more coincident points than a wave can keep apart (passed on to the general
+    search), and queries off the target."""
+    rng = np.random.default_rng(11)
+    dense = (rng.random((40000, 3)) * [30, 30, 4]).astype(np.float32)          # ~3000 per box
+    sparse = (rng.random((300, 3)) * 400).astype(np.float32)
+    heap = np.repeat(np.float32([[5, 5, 5], [6, 5, 5]]), [100, 3], axis=0)      # 100 coincident
+    for tgt in (dense, sparse, np.concatenate([dense[:2000], heap])):
+        ctx.set_target(tgt, np.zeros_like(tgt))
+        tree = po.KDTree(tgt)
+        q = np.concatenate([tgt[:300], (tgt[:100] + rng.normal(size=(100, 3)) * 3).astype(np.float32),
+                            np.float32([[5, 5, 5.01], [-50, 10, 2]])])
+        for k in (1, 2, 7, 20, 32):
+            gi, gd = ctx.knn(q, k)
+            oi, od = tree.knn(q, k)
+            assert np.array_equal(gi, oi) and np.array_equal(gd, od), (len(tgt), k)
+
+
 def test_far_queries_use_the_exhaustive_pass(ctx, po, synth32):
     tgt = synth32["target"]
     ctx.set_target(tgt, synth32["normals"])

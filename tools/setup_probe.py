@@ -1,6 +1,6 @@
 """Development probe: set-up costs at 1M points (grid build, normal estimation, k-NN)."""
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import stereovision_amd as sv
 from stereovision_amd import synth
