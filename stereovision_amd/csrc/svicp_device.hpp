@@ -1599,15 +1599,20 @@ __global__ __launch_bounds__(kBlockThreads) void knn_wave_kernel(
             const float rho = ring_box(g, qx, qy, qz, cx, cy, cz, ring, x0, x1, y0, y1, z0, z1);
             const int bx0 = x0 >> 2, nbxs = (x1 >> 2) - bx0 + 1, ny = y1 - y0 + 1;
             const int nseg = nbxs * ny * (z1 - z0 + 1);
+            // quotients by multiplication: (s + 0.5) / d is at least 0.5 / d from an integer and
+            // s < 2^11, d <= 18, so the reciprocal's rounding cannot carry it across one
+            const float inv_nbxs = __builtin_amdgcn_rcpf((float)nbxs), inv_ny = __builtin_amdgcn_rcpf((float)ny);
             best = kNone;
             kept = 0;
+            unsigned last_t = kNanBits;          // every kept key's distance bits are <= this
             for (int sg = 0; sg < nseg && !gave_up; sg += 64) {
                 // this lane's run: segment (z, y, block in x)
                 unsigned s = 0;
                 int len = 0;
                 if (sg + lane < nseg) {
-                    const int row = (sg + lane) / nbxs, bx = bx0 + (sg + lane) - row * nbxs;
-                    const int zr = row / ny, y = y0 + row - zr * ny, z = z0 + zr;
+                    const int row = (int)(((float)(sg + lane) + 0.5f) * inv_nbxs);
+                    const int bx = bx0 + (sg + lane) - row * nbxs;
+                    const int zr = (int)(((float)row + 0.5f) * inv_ny), y = y0 + row - zr * ny, z = z0 + zr;
                     const int rank = g.dir[((z >> 2) * g.nby + (y >> 2)) * g.nbx + bx];
                     if (rank >= 0) {
                         const int xa = max(x0, bx * 4), xb = min(x1, bx * 4 + 3);
@@ -1624,19 +1629,23 @@ __global__ __launch_bounds__(kBlockThreads) void knn_wave_kernel(
                     // run heads of this round; the run under way at `base` heads position 0
                     wave_lds_sync();
 #pragma unroll
-                    for (int c = 0; c < kKnnWaveChunks; ++c)
-                        if (c * 64 < here) my_head[c * 64 + lane] = 0;
+                    for (int c = 0; c < kKnnWaveChunks; ++c) {
+                        if (c * 64 >= here) break;
+                        my_head[c * 64 + lane] = 0;
+                    }
                     wave_lds_sync();
                     if (len > 0 && incl > base && excl < base + kKnnWaveRound)
                         my_head[max(excl - base, 0)] = lane + 1;
                     wave_lds_sync();
 
                     unsigned long long key[kKnnWaveChunks];
+#pragma unroll
+                    for (int c = 0; c < kKnnWaveChunks; ++c) key[c] = kNone;
                     int run_before = 0;
 #pragma unroll
                     for (int c = 0; c < kKnnWaveChunks; ++c) {
-                        key[c] = kNone;
-                        if (c * 64 < here) {
+                        if (c * 64 >= here) break;
+                        {
                             const int p = c * 64 + lane;
                             const int h = max(wave_inclusive_max(my_head[p]), run_before);
                             run_before = __builtin_amdgcn_readlane(h, 63);
@@ -1656,23 +1665,39 @@ __global__ __launch_bounds__(kBlockThreads) void knn_wave_kernel(
                     auto count_within = [&](unsigned t) {
                         int cnt = __popcll(__ballot((unsigned)(best >> 32) <= t));
 #pragma unroll
-                        for (int c = 0; c < kKnnWaveChunks; ++c)
-                            if (c * 64 < here) cnt += __popcll(__ballot((unsigned)(key[c] >> 32) <= t));
+                        for (int c = 0; c < kKnnWaveChunks; ++c) {
+                            if (c * 64 >= here) break;
+                            cnt += __popcll(__ballot((unsigned)(key[c] >> 32) <= t));
+                        }
                         return cnt;
                     };
                     unsigned t = kNanBits;
                     if (here + kept > 64) {
+                        // the first tries are guesses: on a surface the count grows about linearly
+                        // with the squared distance, so one count tells where the middle of the
+                        // window lies; then plain bisection of the bit patterns
                         long long lo = -1, hi = kNanBits;      // #(<= lo) < k, #(<= hi) > 64
-                        for (;;) {
+                        float guess = kept > 0 && last_t < 0x7f800000u ? __uint_as_float(last_t)
+                                      : rho < INFINITY                  ? rho * rho
+                                                                        : 0.f;
+                        const float aim = 0.5f * (float)(k + 64);
+                        for (int tries = 0;; ++tries) {
                             if (hi - lo < 2) { gave_up = true; break; }
-                            const long long mid = (lo + hi) >> 1;
+                            long long mid = (lo + hi) >> 1;
+                            if (tries < 4 && guess > 0.f) {
+                                const long long gb = __float_as_uint(guess);
+                                if (gb > lo && gb < hi) mid = gb;
+                            }
                             const int cnt = count_within((unsigned)mid);
                             if (cnt < k) lo = mid;
                             else if (cnt > 64) hi = mid;
                             else { t = (unsigned)mid; break; }
+                            guess = __uint_as_float((unsigned)mid) *
+                                    (cnt > 0 ? aim * __builtin_amdgcn_rcpf((float)cnt) : 4.f);
                         }
                         if (gave_up) break;
                     }
+                    last_t = t;
                     // pack the keys within t: one per lane
                     int pos = 0;
                     auto pack = [&](unsigned long long v) {
@@ -1685,25 +1710,63 @@ __global__ __launch_bounds__(kBlockThreads) void knn_wave_kernel(
                     };
                     pack(best);
 #pragma unroll
-                    for (int c = 0; c < kKnnWaveChunks; ++c)
-                        if (c * 64 < here) pack(key[c]);
+                    for (int c = 0; c < kKnnWaveChunks; ++c) {
+                        if (c * 64 >= here) break;
+                        pack(key[c]);
+                    }
                     wave_lds_sync();
                     kept = pos;
                     best = lane < kept ? my_picked[lane] : kNone;
                 }
             }
             if (gave_up) break;
+            // fewer kept keys, fewer steps below: a second bound with k .. k + 4 keys within it,
+            // when the distances allow one (one compare and one count per try)
+            if (kept > k + 4) {
+                long long lo = -1, hi = last_t;            // #(<= lo) < k, #(<= hi) > k + 4
+                float guess = last_t < 0x7f800000u
+                                  ? __uint_as_float(last_t) * ((float)(k + 2) * __builtin_amdgcn_rcpf((float)kept))
+                                  : 0.f;
+                for (int tries = 0; hi - lo >= 2; ++tries) {
+                    long long mid = (lo + hi) >> 1;
+                    if (tries < 2 && guess > 0.f) {
+                        const long long gb = __float_as_uint(guess);
+                        if (gb > lo && gb < hi) mid = gb;
+                    }
+                    const int cnt = __popcll(__ballot((unsigned)(best >> 32) <= (unsigned)mid));
+                    if (cnt < k) lo = mid;
+                    else if (cnt > k + 4) hi = mid;
+                    else {
+                        // pack again: the keys within the bound to lanes 0 .. cnt - 1
+                        const bool in = (unsigned)(best >> 32) <= (unsigned)mid;
+                        const unsigned long long m = __ballot(in);
+                        wave_lds_sync();
+                        if (in) my_picked[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = best;
+                        wave_lds_sync();
+                        kept = cnt;
+                        best = lane < kept ? my_picked[lane] : kNone;
+                        break;
+                    }
+                    guess = __uint_as_float((unsigned)mid) *
+                            (cnt > 0 ? (float)(k + 2) * __builtin_amdgcn_rcpf((float)cnt) : 4.f);
+                }
+            }
             // place of each kept key among the kept keys (distinct: the index is part of a key)
+            // (lanes from `kept` on hold kNone, which is below nothing: four at a time)
             place = 0;
-            for (int j = 0; j < kept; ++j) {
-                const unsigned lo = __builtin_amdgcn_readlane((unsigned)best, j);
-                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(best >> 32), j);
-                place += (((unsigned long long)hi << 32) | lo) < best ? 1 : 0;
+            for (int j = 0; j < kept; j += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)best, j + u);
+                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(best >> 32), j + u);
+                    place += (((unsigned long long)hi << 32) | lo) < best ? 1 : 0;
+                }
             }
             if (rho == INFINITY) {
                 done = true;
             } else if (kept >= k && rho > 0.f) {
-                const unsigned long long m = __ballot(lane < kept && place == k - 1);
+                const unsigned long long m = __ballot(best != kNone && place == k - 1);
                 const int who = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
                 const float dk = __uint_as_float(__builtin_amdgcn_readlane((unsigned)(best >> 32), who));
                 done = dk <= rho * rho;
@@ -1711,7 +1774,7 @@ __global__ __launch_bounds__(kBlockThreads) void knn_wave_kernel(
         }
         if (done) {
             const int have = min(kept, k);
-            if (lane < kept && place < k) {
+            if (best != kNone && place < k) {
                 idx_out[i * k + place] = (int)(unsigned)best;
                 d2_out[i * k + place] = __uint_as_float((unsigned)(best >> 32));
             }
