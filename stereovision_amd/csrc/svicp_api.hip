@@ -618,8 +618,13 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
         hipLaunchKernelGGL(fill_cells_kernel, dim3(cdiv((long long)nranked * 64, 256)), dim3(256), 0,
                            ctx->stream, g, ctx->keys_b.as<unsigned long long>(), (int)m,
                            ctx->block_of_rank.as<int>(), nranked, ctx->run2.as<uint2>(),
-                           ctx->end1.as<unsigned>(), ctx->quad.as<uint4>());
+                           ctx->end1.as<unsigned>());
         LAUNCHCHK("fill_cells_kernel");
+        g.dir = ctx->dir.as<int>();
+        hipLaunchKernelGGL(fill_quads_kernel, dim3(cdiv((long long)nranked * 64, 256)), dim3(256), 0,
+                           ctx->stream, g, ctx->block_of_rank.as<int>(), nranked,
+                           ctx->run2.as<uint2>(), ctx->quad.as<uint4>());
+        LAUNCHCHK("fill_quads_kernel");
     }
     g.dir = ctx->dir.as<int>();
     g.run2 = ctx->run2.as<uint2>();

@@ -1857,17 +1857,30 @@ __global__ __launch_bounds__(kBlockThreads) void normals_kernel(const float *__r
     if (p >= m) return;
     double W[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
     const float kf = (float)k;
-    for (int t = 0; t < k; ++t) {
-        int id = knn_idx[p * k + t];
-        if (id < 0) continue;
-        float c[3] = { ref_aos[3 * (size_t)id], ref_aos[3 * (size_t)id + 1], ref_aos[3 * (size_t)id + 2] };
+    // four neighbours at a time: their indices, then their coordinates, are asked for together
+    // (one after the other, each neighbour costs two round trips to memory); the sums still
+    // take the terms in neighbour order
+    for (int t0 = 0; t0 < k; t0 += 4) {
+        int id[4];
+        float c[4][3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int u = 0; u < 4; ++u) id[u] = t0 + u < k ? knn_idx[p * k + t0 + u] : -1;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float term = __fdiv_rn(__fmul_rn(c[j], c[i]), kf);
-                W[j][i] += (double)term;
-            }
+        for (int u = 0; u < 4; ++u) {
+            const size_t at = 3 * (size_t)max(id[u], 0);
+            c[u][0] = ref_aos[at]; c[u][1] = ref_aos[at + 1]; c[u][2] = ref_aos[at + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (id[u] < 0) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    float term = __fdiv_rn(__fmul_rn(c[u][j], c[u][i]), kf);
+                    W[j][i] += (double)term;
+                }
+        }
     }
     double V[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
     for (int sweep = 0; sweep < 64; ++sweep) {
@@ -2001,11 +2014,27 @@ __device__ __forceinline__ unsigned lower_bound_key(const unsigned long long *ke
     return (unsigned)lo;
 }
 
-// one thread per cell of every ranked block
+// First position at or after `lo` whose key is not below `key`, for a position expected
+// close to `lo`: doubling steps, then bisection of the last step.  keys[lo - 1] < key.
+__device__ __forceinline__ unsigned lower_bound_from(const unsigned long long *keys, unsigned lo,
+                                                     int m, unsigned long long key)
+{
+    unsigned step = 16;
+    while (lo + step < (unsigned)m && keys[lo + step] < key) { lo += step + 1; step *= 2; }
+    unsigned hi = min(lo + step, (unsigned)m);
+    while (lo < hi) {
+        unsigned mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// One thread per cell of every ranked block: where the cell's points start and end in the
+// sorted target, and where the next cell's in x end (one search of the whole array, two
+// short ones from its result).
 __global__ void fill_cells_kernel(GridDesc g, const unsigned long long *__restrict__ keys, int m,
                                   const int *__restrict__ block_of_rank, int nranked,
-                                  uint2 *__restrict__ run2, unsigned *__restrict__ end1,
-                                  uint4 *__restrict__ quad)
+                                  uint2 *__restrict__ run2, unsigned *__restrict__ end1)
 {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)nranked * 64) return;
@@ -2017,19 +2046,31 @@ __global__ void fill_cells_kernel(GridDesc g, const unsigned long long *__restri
     if (cx < g.nx && cy < g.ny && cz < g.nz) {
         unsigned long long key = ((unsigned long long)cz * g.ny + cy) * g.nx + cx;
         s = lower_bound_key(keys, m, key);
-        e1 = lower_bound_key(keys, m, key + 1);
-        e2 = (cx + 1 < g.nx) ? lower_bound_key(keys, m, key + 2) : e1;
+        e1 = lower_bound_from(keys, s, m, key + 1);
+        e2 = (cx + 1 < g.nx) ? lower_bound_from(keys, e1, m, key + 2) : e1;
     }
     run2[t] = make_uint2(s, e2);
     end1[t] = e1;
-    // the runs of the neighbours in y, in z and in both
-    uint2 nb[4] = { make_uint2(s, e2), make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u) };
+}
+
+// The four runs a 2x2x2 probe from each cell walks: the cell's own run2 and those of its
+// neighbours in y, in z and in both, read from the table fill_cells_kernel wrote.  A
+// neighbour outside the grid or in an unranked block (no point in its run) gives an empty run.
+__global__ void fill_quads_kernel(GridDesc g, const int *__restrict__ block_of_rank, int nranked,
+                                  const uint2 *__restrict__ run2, uint4 *__restrict__ quad)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)nranked * 64) return;
+    int rank = (int)(t >> 6), local = (int)(t & 63);
+    int b = block_of_rank[rank];
+    int bx = b % g.nbx, by = (b / g.nbx) % g.nby, bz = b / (g.nbx * g.nby);
+    int cx = bx * 4 + (local & 3), cy = by * 4 + ((local >> 2) & 3), cz = bz * 4 + (local >> 4);
+    uint2 nb[4] = { run2[t], make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u) };
     for (int r = 1; r < 4; ++r) {
         const int y = cy + (r & 1), z = cz + (r >> 1);
         if (cx < g.nx && y < g.ny && z < g.nz) {
-            const unsigned long long key = ((unsigned long long)z * g.ny + y) * g.nx + cx;
-            nb[r].x = lower_bound_key(keys, m, key);
-            nb[r].y = lower_bound_key(keys, m, key + (cx + 1 < g.nx ? 2 : 1));
+            const int nrank = g.dir[dir_index(g, cx, y, z)];
+            if (nrank >= 0) nb[r] = run2[(long long)nrank * 64 + cell_local(cx, y, z)];
         }
     }
     quad[2 * t] = make_uint4(nb[0].x, nb[0].y, nb[1].x, nb[1].y);
