@@ -58,16 +58,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    # SVICP_BENCH_BACKEND=gloo rehearses the multi-rank paths where the ranks outnumber the
+    # GPUs (ranks then share devices and the exchanges go through the host); the default is
+    # RCCL, one rank per GPU
+    backend = os.environ.get("SVICP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     def barrier():
+        torch.cuda.synchronize()
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if not distributed:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local}" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     n = args.side * args.side
     tgt, nrm, src, pose = synth.make_pair(args.side, pair=rank)
@@ -100,10 +117,7 @@ def main():
     elapsed = time.perf_counter() - t0
     region_ms = ev_a.elapsed_time(ev_b)
     launch_region_ms = region_ms / (args.steps * args.iters)
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
     value = world * args.steps * args.iters / elapsed
 
     # ---- per-kernel durations: the same steps, eager, HIP events on the
@@ -181,9 +195,7 @@ def main():
                 Ts, _ = run_sharded(eng, args.iters)
             barrier()
             dt = time.perf_counter() - t0
-            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            dt = max_over_ranks(dt)
         else:
             sctx.run(args.iters)
             torch.cuda.synchronize()
@@ -221,10 +233,7 @@ def main():
             batch.run(args.iters)
         barrier()
         dt = time.perf_counter() - t0
-        if distributed:
-            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = max_over_ranks(dt)
         batched = {
             "workload": f"{args.batch_pairs} independent pairs of 65536 points per rank, "
                         f"{args.iters} iterations, per-pair pose, one launch per iteration",
@@ -256,9 +265,7 @@ def main():
                 evaluate_sharded(eng, cstart, 5, V, vb, ve, fetch=False)
             barrier()
             dt = time.perf_counter() - t0
-            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            eval_ms = float(t.item()) / reps * 1e3
+            eval_ms = max_over_ranks(dt) / reps * 1e3
         else:
             eng.set_params(cstart, 5)
             eval_ms = eng.ev.time_eval(reps)      # HIP events around back-to-back evaluations
