@@ -291,6 +291,18 @@ def main():
             for _ in range(20):
                 eng.ev.solve_damped(1e-3)
             calibration["damped_step_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+        else:
+            # the same step with the views split: every rank eliminates its own views, the
+            # shared system is summed over the ranks and solved by each, the step is gathered
+            from stereovision_amd.calib import solve_damped_sharded
+            evaluate_sharded(eng, cstart, 5, V, vb, ve, fetch=False)
+            solve_damped_sharded(eng, 1e-3, 5, V, vb, ve)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                solve_damped_sharded(eng, 1e-3, 5, V, vb, ve)
+            barrier()
+            calibration["damped_step_ms"] = max_over_ranks(time.perf_counter() - t0) / 20 * 1e3
         if rank == 0 and world == 1 and args.cpu_iters > 0:
             from oracle import pyoracle as po
             t0 = time.perf_counter()

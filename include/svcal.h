@@ -75,7 +75,7 @@ int svcal_fetch(svcal_ctx *ctx, svcal_blocks *out);
  * parameter vector's length and order; predicted_out (may be NULL): step^T (lam step - G), the
  * denominator of the gain ratio (:312-313).  SVICP_ERR_SINGULAR when a block is not positive
  * definite.  Not for a context whose sums were replaced by svcal_shard_import (the views of
- * the other ranks are not here). */
+ * the other ranks are not here: svcal_solve_begin / svcal_solve_end below). */
 int svcal_solve_damped(svcal_ctx *ctx, double lam, double *step_out, double *predicted_out);
 
 /* |e|^2 of the last svcal_eval alone (two doubles come back instead of every block). */
@@ -95,6 +95,22 @@ int svcal_set_stream(svcal_ctx *ctx, void *hip_stream, int use_own);
  * of the whole problem and the per-view blocks (LE, EE, gE) of this context's views. */
 int svcal_shard_export(svcal_ctx *ctx, double *dev_sums272);
 int svcal_shard_import(svcal_ctx *ctx, const double *dev_sums272);
+
+/* The damped step with the views split over several contexts (no counterpart in the
+ * reference; after svcal_shard_import, so every context holds the sums of the whole
+ * problem).  svcal_solve_begin eliminates this context's views and copies their summed
+ * contribution to the shared system (SVCAL_SOLVE_SUMS doubles) into a caller's device
+ * buffer; the caller adds the buffers of all contexts (an all-reduce) and hands the total to
+ * svcal_solve_end, which solves the shared system (every context the same one) and this
+ * context's views.  step_out: this context's parameter vector (shared parameters, its own
+ * views' six each, the stereo pose); predicted_out[0]: the shared parameters' part of
+ * step^T (lam step - G), the same in every context; predicted_out[1]: the part of this
+ * context's views (the caller adds [1] over the contexts and [0] once).  With one context,
+ * begin followed by end is svcal_solve_damped. */
+#define SVCAL_SOLVE_SUMS 90
+int svcal_solve_begin(svcal_ctx *ctx, double lam, double *dev_sums90);
+int svcal_solve_end(svcal_ctx *ctx, double lam, const double *dev_sums90, double *step_out,
+                    double predicted_out[2]);
 
 /* CStereoCameraRectification::doImageRectify
  * (Calibration/CStereoCameraRectification.cpp:60-143): for every pixel (i, j) of the

@@ -25,6 +25,8 @@ class _Blocks(C.Structure):
                                    "residual")] + [("sq_residual", C.c_double)]
 
 
+SOLVE_SUMS = 90          # SVCAL_SOLVE_SUMS: a view's contribution to the shared system, nI x (nI + 1), nI <= 9
+
 CAL_SYMBOLS = {
     "svcal_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "svcal_destroy": (C.c_int, [C.c_void_p]),
@@ -35,6 +37,8 @@ CAL_SYMBOLS = {
     "svcal_fetch": (C.c_int, [C.c_void_p, C.POINTER(_Blocks)]),
     "svcal_sq_residual": (C.c_int, [C.c_void_p, _dp]),
     "svcal_solve_damped": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp]),
+    "svcal_solve_begin": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
+    "svcal_solve_end": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, _dp, _dp]),
     "svcal_time_eval": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "svcal_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "svcal_shard_export": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -140,6 +144,20 @@ class ReprojectionEvaluator:
         pred = C.c_double(0.0)
         self._check(self._lib.svcal_solve_damped(self._h, C.c_double(lam), _d(step), C.byref(pred)))
         return step, pred.value
+
+    def solve_begin(self, lam, dev_ptr):
+        """First half of the damped step for views split over contexts: this context's views
+        eliminated, their SOLVE_SUMS summed contributions copied to the device buffer."""
+        self._check(self._lib.svcal_solve_begin(self._h, C.c_double(lam), C.c_void_p(int(dev_ptr))))
+
+    def solve_end(self, lam, dev_ptr):
+        """Second half, from the contributions added over all contexts: (this context's step,
+        the shared parameters' part of step^T (lam step - G), its own views' part)."""
+        step = np.empty(self.n_params(self.k), np.float64)
+        pred = np.zeros(2, np.float64)
+        self._check(self._lib.svcal_solve_end(self._h, C.c_double(lam), C.c_void_p(int(dev_ptr)),
+                                              _d(step), _d(pred)))
+        return step, float(pred[0]), float(pred[1])
 
     def evaluate(self, params, k=5, want_residual=True):
         self.set_params(params, k)
@@ -334,6 +352,7 @@ class HipCalEngine:
         self.ev = ReprojectionEvaluator(world_xy, left_xy, right_xy, self.dev.index or 0)
         self.stereo = self.ev.stereo
         self.buf = torch.zeros(272, dtype=torch.float64, device=self.dev)
+        self.cbuf = torch.zeros(SOLVE_SUMS, dtype=torch.float64, device=self.dev)
         self.ev.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
 
     def set_params(self, p, k):
@@ -352,6 +371,29 @@ class HipCalEngine:
     def fetch(self):
         return self.ev.fetch(want_residual=False)
 
+    def sq_residual(self):
+        return self.ev.sq_residual()
+
+    def solve_begin(self, lam):
+        self.ev.solve_begin(lam, self.cbuf.data_ptr())
+        return self.cbuf
+
+    def solve_end(self, lam, t):
+        return self.ev.solve_end(lam, t.data_ptr())
+
+
+def _all_reduce_sum(t, group=None):
+    """Sum over the ranks, in place: on the device with the nccl backend, through the host
+    otherwise."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
 
 def evaluate_sharded(engine, params, k, V_total, begin, end, group=None, fetch=True):
     """One evaluation with the views split over the ranks of a torch.distributed group.
@@ -361,15 +403,73 @@ def evaluate_sharded(engine, params, k, V_total, begin, end, group=None, fetch=T
     import torch.distributed as dist
     engine.set_params(split_views(params, k, V_total, engine.stereo, begin, end), k)
     engine.eval()
-    t = engine.export_sums()
-    if t.is_cuda and dist.get_backend(group) != "nccl":
-        host = t.cpu()
-        dist.all_reduce(host, group=group)
-        t.copy_(host)
-    else:
-        dist.all_reduce(t, group=group)
+    t = _all_reduce_sum(engine.export_sums(), group)
     engine.import_sums(t)
     return engine.fetch() if fetch else None
+
+
+def solve_damped_sharded(engine, lam, k, V_total, begin, end, group=None):
+    """The damped step of the whole problem with the views split over the ranks, after
+    evaluate_sharded.  Two exchanges: the views' contributions to the shared system
+    (SOLVE_SUMS doubles) before it is solved, the same on every rank; then the step itself,
+    every rank filling in its own views (and rank 0 the shared parameters), with the ranks'
+    parts of step^T (lam step - G) in one more slot.  Returns (step of the whole problem,
+    step^T (lam step - G)), the same on every rank."""
+    import torch
+    import torch.distributed as dist
+    t = _all_reduce_sum(engine.solve_begin(lam), group)
+    local, pred_shared, pred_views = engine.solve_end(lam, t)
+    nI = 4 + k
+    e0 = 2 * nI if engine.stereo else nI
+    P = e0 + 6 * V_total + (6 if engine.stereo else 0)
+    whole = np.zeros(P + 1)
+    whole[e0 + 6 * begin:e0 + 6 * end] = local[e0:e0 + 6 * (end - begin)]
+    whole[P] = pred_views
+    if dist.get_rank(group) == 0:
+        whole[:e0] = local[:e0]
+        if engine.stereo:
+            whole[e0 + 6 * V_total:P] = local[e0 + 6 * (end - begin):]
+        whole[P] += pred_shared
+    w = torch.from_numpy(whole)
+    if dist.get_backend(group) == "nccl":
+        w = w.to(t.device)
+    dist.all_reduce(w, group=group)
+    whole = w.cpu().numpy()
+    return whole[:P].copy(), float(whole[P])
+
+
+def lm_refine_sharded(engine, params, k, V_total, begin, end, group=None, max_iter=100, verbose=False):
+    """lm_refine with the views split over the ranks: every rank runs the same loop on the
+    whole parameter vector and evaluates and solves its own views; per trial step one
+    all-reduce of 272 sums (evaluation), one of SOLVE_SUMS and one of the step (solve)."""
+    x = np.array(params, np.float64)
+
+    def evaluate(p):
+        evaluate_sharded(engine, p, k, V_total, begin, end, group, fetch=False)
+        return engine.sq_residual()
+
+    err2 = evaluate(x)
+    lam, v = 1.0e-3, 2.0
+    for it in range(max_iter):
+        step, denom = solve_damped_sharded(engine, lam, k, V_total, begin, end, group)
+        if np.linalg.norm(step) < 1.0e-5:
+            break
+        new2 = evaluate(x + step)
+        r = (err2 - new2) / denom
+        if verbose:
+            print(f"iter {it}: |e| {np.sqrt(err2):.6g} -> {np.sqrt(new2):.6g}, gain {r:.3g}")
+        if r > 0:
+            x = x + step
+            err2 = new2
+            if np.sqrt(err2) < 1.0e-3:
+                break
+            lam *= max(1.0 / 3.0, 1.0 - (2.0 * r - 1.0) ** 3)
+            v = 2.0
+        else:
+            evaluate(x)
+            lam *= v
+            v *= 2.0
+    return x, np.sqrt(err2)
 
 
 def stereo_rectify(KL, KR, R, T):

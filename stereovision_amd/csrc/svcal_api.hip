@@ -25,8 +25,10 @@ struct svcal_ctx {
     size_t cap_params = 0;
     // the damped solve: per-view solutions and contributions, shared step, whole step, flags
     double *sv_W = nullptr, *sv_contrib = nullptr, *sv_dc = nullptr, *sv_step = nullptr, *sv_pred = nullptr;
+    double *sv_csum = nullptr;       // the views' summed contribution to the shared system
     int *sv_flags = nullptr;
     int sv_views = 0;
+    bool solve_begun = false;        // svcal_solve_begin ran for the blocks now on the device
 };
 
 namespace {
@@ -69,11 +71,13 @@ void free_obs(svcal_ctx *ctx)
     void *bufs[] = { ctx->world, ctx->left, ctx->right, ctx->gram_view, ctx->gram_sum, ctx->residual };
     for (void *b : bufs) if (b) (void)hipFree(b);
     ctx->world = ctx->left = ctx->right = ctx->gram_view = ctx->gram_sum = ctx->residual = nullptr;
-    void *sv[] = { ctx->sv_W, ctx->sv_contrib, ctx->sv_dc, ctx->sv_step, ctx->sv_pred, ctx->sv_flags };
+    void *sv[] = { ctx->sv_W, ctx->sv_contrib, ctx->sv_dc, ctx->sv_step, ctx->sv_pred, ctx->sv_flags,
+                   ctx->sv_csum };
     for (void *b : sv) if (b) (void)hipFree(b);
-    ctx->sv_W = ctx->sv_contrib = ctx->sv_dc = ctx->sv_step = ctx->sv_pred = nullptr;
+    ctx->sv_W = ctx->sv_contrib = ctx->sv_dc = ctx->sv_step = ctx->sv_pred = ctx->sv_csum = nullptr;
     ctx->sv_flags = nullptr;
     ctx->sv_views = 0;
+    ctx->solve_begun = false;
 }
 
 int param_count(const svcal_ctx *ctx, int k)
@@ -199,6 +203,7 @@ int svcal_eval(svcal_ctx *ctx)
     e = hipGetLastError();
     if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "cal_reduce_kernel", e);
     ctx->evaluated = true;
+    ctx->solve_begun = false;
     return SVICP_OK;
 }
 
@@ -261,43 +266,65 @@ int svcal_sq_residual(svcal_ctx *ctx, double *out)
     return SVICP_OK;
 }
 
-int svcal_solve_damped(svcal_ctx *ctx, double lam, double *step_out, double *predicted_out)
+namespace {
+int ensure_solve_buffers(svcal_ctx *ctx)
 {
-    if (!ctx || !step_out) return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_damped: NULL argument");
-    if (!ctx->evaluated) return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_damped: nothing evaluated yet");
+    const int V = ctx->V;
+    if (ctx->sv_views == V) return SVICP_OK;
+    void *sv[] = { ctx->sv_W, ctx->sv_contrib, ctx->sv_dc, ctx->sv_step, ctx->sv_pred, ctx->sv_flags,
+                   ctx->sv_csum };
+    for (void *b : sv) if (b) CHK(hipFree(b));
+    ctx->sv_W = ctx->sv_contrib = ctx->sv_dc = ctx->sv_step = ctx->sv_pred = ctx->sv_csum = nullptr;
+    ctx->sv_flags = nullptr;
+    ctx->sv_views = 0;
+    // sized for the longest parameter vector (five distortion terms, stereo)
+    CHK(hipMalloc((void **)&ctx->sv_W, sizeof(double) * (size_t)V * 6 * 10));
+    CHK(hipMalloc((void **)&ctx->sv_contrib, sizeof(double) * (size_t)V * 9 * 10));
+    CHK(hipMalloc((void **)&ctx->sv_dc, sizeof(double) * (kMaxShared + 1)));
+    CHK(hipMalloc((void **)&ctx->sv_step, sizeof(double) * (2 * 9 + 6 * (size_t)V + 6)));
+    CHK(hipMalloc((void **)&ctx->sv_pred, sizeof(double) * (size_t)V));
+    CHK(hipMalloc((void **)&ctx->sv_flags, sizeof(int)));
+    CHK(hipMalloc((void **)&ctx->sv_csum, sizeof(double) * kSolveSums));
+    ctx->sv_views = V;
+    return SVICP_OK;
+}
+
+// the views' blocks eliminated; their summed contribution to the shared system in sv_csum
+int solve_first_half(svcal_ctx *ctx, double lam, const char *who)
+{
+    if (!ctx->evaluated) return cfail(ctx, SVICP_ERR_ARG, "svcal_solve: nothing evaluated yet");
     if (!(lam >= 0.0) || !std::isfinite(lam))
-        return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_damped: the damping must be finite and >= 0");
+        return cfail(ctx, SVICP_ERR_ARG, "svcal_solve: the damping must be finite and >= 0");
     CHK(hipSetDevice(ctx->device));
-    const int V = ctx->V, nI = 4 + ctx->k, P = param_count(ctx, ctx->k);
-    if (ctx->sv_views != V) {
-        void *sv[] = { ctx->sv_W, ctx->sv_contrib, ctx->sv_dc, ctx->sv_step, ctx->sv_pred, ctx->sv_flags };
-        for (void *b : sv) if (b) CHK(hipFree(b));
-        ctx->sv_W = ctx->sv_contrib = ctx->sv_dc = ctx->sv_step = ctx->sv_pred = nullptr;
-        ctx->sv_flags = nullptr;
-        ctx->sv_views = 0;
-        // sized for the longest parameter vector (five distortion terms, stereo)
-        CHK(hipMalloc((void **)&ctx->sv_W, sizeof(double) * (size_t)V * 6 * 10));
-        CHK(hipMalloc((void **)&ctx->sv_contrib, sizeof(double) * (size_t)V * 9 * 10));
-        CHK(hipMalloc((void **)&ctx->sv_dc, sizeof(double) * (kMaxShared + 1)));
-        CHK(hipMalloc((void **)&ctx->sv_step, sizeof(double) * (2 * 9 + 6 * (size_t)V + 6)));
-        CHK(hipMalloc((void **)&ctx->sv_pred, sizeof(double) * (size_t)V));
-        CHK(hipMalloc((void **)&ctx->sv_flags, sizeof(int)));
-        ctx->sv_views = V;
-    }
+    int rc = ensure_solve_buffers(ctx);
+    if (rc) return rc;
+    const int V = ctx->V, nI = 4 + ctx->k;
     CHK(hipMemsetAsync(ctx->sv_flags, 0, sizeof(int), ctx->stream));
-    const int blocks = (V + 63) / 64;
-    hipLaunchKernelGGL(cal_view_eliminate_kernel, dim3(blocks), dim3(64), 0, ctx->stream, ctx->gram_view,
-                       V, nI, lam, ctx->sv_W, ctx->sv_contrib, ctx->sv_flags);
+    hipLaunchKernelGGL(cal_view_eliminate_kernel, dim3((V + 63) / 64), dim3(64), 0, ctx->stream,
+                       ctx->gram_view, V, nI, lam, ctx->sv_W, ctx->sv_contrib, ctx->sv_flags);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "cal_view_eliminate_kernel", e);
-    hipLaunchKernelGGL(cal_shared_solve_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->gram_sum,
-                       ctx->sv_contrib, V, nI, ctx->stereo, lam, ctx->sv_dc, ctx->sv_flags);
+    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, who, e);
+    hipLaunchKernelGGL(cal_contrib_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->sv_contrib, V, nI,
+                       ctx->sv_csum);
     e = hipGetLastError();
-    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "cal_shared_solve_kernel", e);
+    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, who, e);
+    return SVICP_OK;
+}
+
+// the shared system solved from sv_csum, the views' steps from it; predicted[0]: the shared
+// parameters' part of step^T (lam step - G), predicted[1]: this context's views' part
+int solve_second_half(svcal_ctx *ctx, double lam, double *step_out, double predicted[2], const char *who)
+{
+    const int V = ctx->V, nI = 4 + ctx->k, P = param_count(ctx, ctx->k);
+    const int blocks = (V + 63) / 64;
+    hipLaunchKernelGGL(cal_shared_solve_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->gram_sum,
+                       ctx->sv_csum, nI, ctx->stereo, lam, ctx->sv_dc, ctx->sv_flags);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, who, e);
     hipLaunchKernelGGL(cal_view_step_kernel, dim3(blocks), dim3(64), 0, ctx->stream, ctx->gram_view,
                        ctx->sv_W, ctx->sv_dc, V, nI, ctx->stereo, lam, ctx->sv_step, ctx->sv_pred);
     e = hipGetLastError();
-    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "cal_view_step_kernel", e);
+    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, who, e);
     std::vector<double> pv(V);
     double shared_pred = 0.0;
     int flags = 0;
@@ -308,14 +335,52 @@ int svcal_solve_damped(svcal_ctx *ctx, double lam, double *step_out, double *pre
     CHK(hipStreamSynchronize(ctx->stream));
     if (flags)
         return cfail(ctx, SVICP_ERR_SINGULAR,
-                     flags & 2 ? "svcal_solve_damped: the shared system is not positive definite"
-                               : "svcal_solve_damped: a view's 6 x 6 block is not positive definite");
-    if (predicted_out) {
-        double s = shared_pred;
-        for (int v = 0; v < V; ++v) s += pv[v];          // in view order, always
-        *predicted_out = s;
-    }
+                     flags & 2 ? "svcal_solve: the shared system is not positive definite"
+                               : "svcal_solve: a view's 6 x 6 block is not positive definite");
+    double s = 0.0;
+    for (int v = 0; v < V; ++v) s += pv[v];              // in view order, always
+    predicted[0] = shared_pred;
+    predicted[1] = s;
     return SVICP_OK;
+}
+}  // namespace
+
+int svcal_solve_damped(svcal_ctx *ctx, double lam, double *step_out, double *predicted_out)
+{
+    if (!ctx || !step_out) return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_damped: NULL argument");
+    int rc = solve_first_half(ctx, lam, "svcal_solve_damped");
+    if (rc) return rc;
+    double pred[2];
+    rc = solve_second_half(ctx, lam, step_out, pred, "svcal_solve_damped");
+    if (rc) return rc;
+    if (predicted_out) *predicted_out = pred[0] + pred[1];
+    return SVICP_OK;
+}
+
+int svcal_solve_begin(svcal_ctx *ctx, double lam, double *dev_sums90)
+{
+    if (!ctx || !dev_sums90) return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_begin: NULL argument");
+    int rc = solve_first_half(ctx, lam, "svcal_solve_begin");
+    if (rc) return rc;
+    CHK(hipMemcpyAsync(dev_sums90, ctx->sv_csum, sizeof(double) * kSolveSums, hipMemcpyDeviceToDevice,
+                       ctx->stream));
+    ctx->solve_begun = true;
+    return SVICP_OK;
+}
+
+int svcal_solve_end(svcal_ctx *ctx, double lam, const double *dev_sums90, double *step_out,
+                    double predicted_out[2])
+{
+    if (!ctx || !dev_sums90 || !step_out || !predicted_out)
+        return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_end: NULL argument");
+    if (!ctx->solve_begun) return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_end: call svcal_solve_begin first");
+    if (!(lam >= 0.0) || !std::isfinite(lam))
+        return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_end: the damping must be finite and >= 0");
+    CHK(hipSetDevice(ctx->device));
+    ctx->solve_begun = false;
+    CHK(hipMemcpyAsync(ctx->sv_csum, dev_sums90, sizeof(double) * kSolveSums, hipMemcpyDeviceToDevice,
+                       ctx->stream));
+    return solve_second_half(ctx, lam, step_out, predicted_out, "svcal_solve_end");
 }
 
 int svcal_set_stream(svcal_ctx *ctx, void *hip_stream, int use_own)

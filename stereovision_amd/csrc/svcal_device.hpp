@@ -384,30 +384,42 @@ __global__ void cal_view_eliminate_kernel(const double *__restrict__ gram_view, 
     }
 }
 
-// One block.  Sums the views' contributions in a fixed order, assembles the damped shared
-// system from the summed triangles, solves it (Cholesky in LDS) and writes the shared part
-// of the step: dc[0 .. nC), followed by dc^T (lam dc - gc) in dc[kMaxShared].
+constexpr int kSolveSums = 9 * 10;   // a view's contribution: nI x (nI + 1) doubles, nI <= 9
+
+// One block.  The views' contributions summed in a fixed order into csum[0 .. kSolveSums)
+// (entries past nI (nI + 1): zero).  With the views split over several devices this is the
+// part of the shared system that has to be added up across them before it is solved.
+__global__ __launch_bounds__(256) void cal_contrib_sum_kernel(const double *__restrict__ contrib,
+                                                              int V, int nI,
+                                                              double *__restrict__ csum)
+{
+    __shared__ double part[256];
+    const int ne = nI * (nI + 1);
+    const int t = threadIdx.x;
+    // entry e by threads e and e + 128, half of the views each
+    const int e = t & 127, half = t >> 7;
+    double s = 0.0;
+    if (e < ne) {
+        const int v0 = half ? V / 2 : 0, v1 = half ? V : V / 2;
+        for (int v = v0; v < v1; ++v) s += contrib[(size_t)v * ne + e];
+    }
+    part[t] = s;
+    __syncthreads();
+    if (t < kSolveSums) csum[t] = t < ne ? part[t] + part[t + 128] : 0.0;
+}
+
+// One block.  Assembles the damped shared system from the summed triangles and the summed
+// contributions of the views, solves it (Cholesky in LDS) and writes the shared part of the
+// step: dc[0 .. nC), followed by dc^T (lam dc - gc) in dc[kMaxShared].
 __global__ __launch_bounds__(256) void cal_shared_solve_kernel(
-    const double *__restrict__ gram_sum, const double *__restrict__ contrib, int V, int nI,
+    const double *__restrict__ gram_sum, const double *__restrict__ csum_in, int nI,
     int stereo, double lam, double *__restrict__ dc_out, int *__restrict__ flags)
 {
     __shared__ double S[kMaxShared][kMaxShared + 1];           // last column: the gradient
-    __shared__ double part[256];
-    __shared__ double csum[9 * 10];
-    const int nc = nI + 1, ne = nI * nc, nC = stereo ? 2 * nI + 6 : nI;
+    __shared__ double csum[kSolveSums];
+    const int nc = nI + 1, nC = stereo ? 2 * nI + 6 : nI;
     const int t = threadIdx.x;
-    // ---- sum over the views: entry e by threads e and e + 128, half of the views each ----
-    {
-        const int e = t & 127, half = t >> 7;
-        double s = 0.0;
-        if (e < ne) {
-            const int v0 = half ? V / 2 : 0, v1 = half ? V : V / 2;
-            for (int v = v0; v < v1; ++v) s += contrib[(size_t)v * ne + e];
-        }
-        part[t] = s;
-    }
-    __syncthreads();
-    if (t < ne) csum[t] = part[t] + part[t + 128];
+    if (t < kSolveSums) csum[t] = csum_in[t];
     for (int i = t; i < kMaxShared * (kMaxShared + 1); i += 256) (&S[0][0])[i] = 0.0;
     __syncthreads();
     // ---- the shared system ----

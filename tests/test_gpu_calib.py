@@ -177,6 +177,56 @@ def test_device_step_equals_host_step(views, stereo, k):
     ev.close()
 
 
+@pytest.mark.parametrize("views,stereo,parts", [(7, True, 2), (7, False, 3), (2000, True, 4)])
+def test_step_with_views_split_over_contexts(views, stereo, parts):
+    """svcal_solve_begin / svcal_solve_end on several contexts of one GPU, each holding a
+    range of the views, the two sums over the contexts added here as an all-reduce would:
+    the assembled step and predicted decrease equal svcal_solve_damped on one context holding
+    every view."""
+    import torch
+    from stereovision_amd.calib import (HipCalEngine, ReprojectionEvaluator, split_views, view_bounds)
+    w, l, r, _, start = synth.make_stereo_views(views=views, perturb=1e-2)
+    nI = 9
+    if not stereo:
+        start = np.concatenate([start[:nI], start[2 * nI: 2 * nI + 6 * views]])
+    whole = ReprojectionEvaluator(w, l, r if stereo else None)
+    whole.evaluate(start, 5, want_residual=False)
+    spans = [view_bounds(views, parts, i) for i in range(parts)]
+    engs = [HipCalEngine(w, l[b:e], r[b:e] if stereo else None, "cuda:0") for b, e in spans]
+    for eng, (b, e) in zip(engs, spans):
+        eng.set_params(split_views(start, 5, views, stereo, b, e), 5)
+        eng.eval()
+    total = torch.stack([eng.export_sums() for eng in engs]).sum(0)
+    for eng in engs:
+        eng.import_sums(total)
+        assert eng.sq_residual() == pytest.approx(whole.sq_residual(), rel=1e-12)
+    e0 = 2 * nI if stereo else nI
+    for lam in (1e-3, 0.7):
+        want, wpred = whole.solve_damped(lam)
+        csum = torch.stack([eng.solve_begin(lam) for eng in engs]).sum(0)
+        got = np.zeros_like(want)
+        pred = 0.0
+        for i, (eng, (b, e)) in enumerate(zip(engs, spans)):
+            step, ps, pv = eng.solve_end(lam, csum)
+            got[e0 + 6 * b:e0 + 6 * e] = step[e0:e0 + 6 * (e - b)]
+            pred += pv
+            if i == 0:
+                got[:e0] = step[:e0]
+                if stereo:
+                    got[e0 + 6 * views:] = step[e0 + 6 * (e - b):]
+                pred += ps
+            else:
+                assert np.array_equal(got[:e0], step[:e0])       # the same shared system everywhere
+        assert np.abs(got - want).max() < 1e-9 * np.abs(want).max()
+        assert pred == pytest.approx(wpred, rel=1e-9)
+    with pytest.raises(Exception):
+        engs[0].eval()
+        engs[0].solve_end(1e-3, csum)             # a new evaluation: begin has to come first
+    whole.close()
+    for eng in engs:
+        eng.ev.close()
+
+
 def test_device_step_argument_errors():
     from stereovision_amd import SvicpError
     from stereovision_amd.calib import ReprojectionEvaluator

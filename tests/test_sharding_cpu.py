@@ -125,6 +125,38 @@ class OracleCalEngine:
     def fetch(self):
         return self.out
 
+    def sq_residual(self):
+        return self.out["sq_residual"]
+
+    # the two halves of the damped step, as svcal_solve_begin / svcal_solve_end split it
+    def solve_begin(self, lam):
+        o, nI = self.out, 4 + self.k
+        EE = o["EE"] + lam * np.einsum("vij,ij->vij", o["EE"], np.eye(6))
+        rhs = np.concatenate([np.transpose(o["LE"], (0, 2, 1)), o["gE"][:, :, None]], axis=2)
+        self.W = np.linalg.solve(EE, rhs)                          # (V, 6, nI + 1)
+        contrib = np.einsum("vaq,vqc->ac", o["LE"], self.W)        # (nI, nI + 1)
+        flat = np.zeros(90)
+        flat[:nI * (nI + 1)] = contrib.ravel()
+        return torch.from_numpy(flat)
+
+    def solve_end(self, lam, t):
+        o, nI = self.out, 4 + self.k
+        csum = t.numpy()[:nI * (nI + 1)].reshape(nI, nI + 1)
+        nC = 2 * nI + 6
+        A, g = np.zeros((nC, nC)), np.zeros(nC)
+        A[:nI, :nI], g[:nI] = o["LL"], o["gL"]
+        A[nI:2 * nI, nI:2 * nI], A[nI:2 * nI, 2 * nI:] = o["RR"], o["RS"]
+        A[2 * nI:, nI:2 * nI], A[2 * nI:, 2 * nI:] = o["RS"].T, o["SS"]
+        g[nI:2 * nI], g[2 * nI:] = o["gR"], o["gS"]
+        S = A + lam * np.diag(np.diag(A))
+        S[:nI, :nI] -= csum[:, :nI]
+        rhs = g.copy()
+        rhs[:nI] -= csum[:, nI]
+        dc = -np.linalg.solve(S, rhs)
+        de = -(self.W[:, :, nI] + np.einsum("vqa,a->vq", self.W[:, :, :nI], dc[:nI]))
+        step = np.concatenate([dc[:2 * nI], de.ravel(), dc[2 * nI:]])
+        return step, float(dc @ (lam * dc - g)), float((de * (lam * de - o["gE"])).sum())
+
 
 def _cal_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
@@ -139,8 +171,12 @@ def _cal_worker(rank, world, port, out_dir):
     b, e = view_bounds(V, world, rank)
     eng = OracleCalEngine(po, w, l[b:e], r[b:e])
     out = evaluate_sharded(eng, start, 5, V, b, e)
+    from stereovision_amd.calib import lm_refine_sharded, solve_damped_sharded
+    step, pred = solve_damped_sharded(eng, 0.05, 5, V, b, e)
+    x, err = lm_refine_sharded(eng, start, 5, V, b, e, max_iter=4)
     np.savez(os.path.join(out_dir, f"cal{rank}.npz"), begin=b, end=e,
-             **{n: out[n] for n in SHARED + ("LE", "EE", "gE")}, sq=out["sq_residual"])
+             **{n: out[n] for n in SHARED + ("LE", "EE", "gE")}, sq=out["sq_residual"],
+             step=step, pred=pred, x=x, err=err)
     dist.destroy_process_group()
 
 
@@ -171,3 +207,20 @@ def test_calibration_views_split_over_two_ranks(po, tmp_path):
         b, e = int(part["begin"]), int(part["end"])
         for n in ("LE", "EE", "gE"):
             assert np.array_equal(part[n], whole[n][b:e])
+    # the damped step and the refinement loop over the two ranks against the same on one
+    from stereovision_amd.calib import lm_refine, solve_damped
+    want, wpred = solve_damped(whole, 5, 7, 0.05)
+    for part in parts:
+        assert np.abs(part["step"] - want).max() < 1e-9 * np.abs(want).max()
+        assert float(part["pred"]) == pytest.approx(wpred, rel=1e-9)
+    assert np.array_equal(parts[0]["x"], parts[1]["x"])
+
+    class Whole:
+        V, stereo = 7, True
+
+        def evaluate(self, p, k, want_residual=False):
+            return po.stereo_eval_sparse(p, k, w, l, r, False)
+
+    xw, ew = lm_refine(Whole(), start, 5, max_iter=4, host_solve=True)
+    assert float(parts[0]["err"]) == pytest.approx(ew, rel=1e-6)
+    assert np.abs(parts[0]["x"] - xw).max() < 1e-6 * np.abs(xw).max()
