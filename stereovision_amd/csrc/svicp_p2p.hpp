@@ -146,9 +146,12 @@ __device__ inline void kabsch_rotation(const double W[9], double R[9])
     for (int k = 0; k < 9; ++k) A[k] = W[k];
     for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0.0;
+#pragma unroll
         for (int p = 0; p < 2; ++p)
+#pragma unroll
             for (int q = p + 1; q < 3; ++q) {
                 double a = 0, b = 0, gm = 0;
+#pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     a += A[3 * r + p] * A[3 * r + p];
                     b += A[3 * r + q] * A[3 * r + q];
@@ -160,6 +163,7 @@ __device__ inline void kabsch_rotation(const double W[9], double R[9])
                 const double zeta = (b - a) / (2.0 * gm);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const double ap = A[3 * r + p], aq = A[3 * r + q];
                     A[3 * r + p] = c * ap - s * aq;
@@ -172,20 +176,30 @@ __device__ inline void kabsch_rotation(const double W[9], double R[9])
         if (off < 1e-15) break;
     }
     double nrm[3];
-    int order[3] = { 0, 1, 2 };
+#pragma unroll
     for (int c = 0; c < 3; ++c) nrm[c] = sqrt(A[c] * A[c] + A[3 + c] * A[3 + c] + A[6 + c] * A[6 + c]);
-    for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2 - i; ++j)
-            if (nrm[order[j]] < nrm[order[j + 1]]) { const int t = order[j]; order[j] = order[j + 1]; order[j + 1] = t; }
-    double U[9], Vs[9];
-    for (int c = 0; c < 3; ++c) {
-        const int o = order[c];
-        for (int r = 0; r < 3; ++r) {
-            Vs[3 * r + c] = V[3 * r + o];
-            U[3 * r + c] = nrm[o] > 0 ? A[3 * r + o] / nrm[o] : 0.0;
+    // columns by descending norm: the exchanges of a bubble sort, on the columns themselves
+    // (constant indices only: an index array would put A and V in scratch memory)
+    auto order = [&](int i, int j) {
+        if (nrm[i] < nrm[j]) {
+            double t = nrm[i]; nrm[i] = nrm[j]; nrm[j] = t;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                t = A[3 * r + i]; A[3 * r + i] = A[3 * r + j]; A[3 * r + j] = t;
+                t = V[3 * r + i]; V[3 * r + i] = V[3 * r + j]; V[3 * r + j] = t;
+            }
         }
-    }
-    if (!(nrm[order[2]] > 0)) {     // complete U to a right-handed basis
+    };
+    order(0, 1); order(1, 2); order(0, 1);
+    double U[9], Vs[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            Vs[3 * r + c] = V[3 * r + c];
+            U[3 * r + c] = nrm[c] > 0 ? A[3 * r + c] / nrm[c] : 0.0;
+        }
+    if (!(nrm[2] > 0)) {     // complete U to a right-handed basis
         U[2] = U[3] * U[7] - U[6] * U[4];
         U[5] = U[6] * U[1] - U[0] * U[7];
         U[8] = U[0] * U[4] - U[3] * U[1];
