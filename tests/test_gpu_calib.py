@@ -241,6 +241,23 @@ def test_device_step_argument_errors():
         ev.solve_damped(-1.0)
     with pytest.raises(SvicpError):
         ev.solve_damped(float("nan"))
+    # the split solve: end without begin, begin with a bad damping, NULL buffers
+    import torch
+    buf = torch.zeros(90, dtype=torch.float64, device="cuda:0")
+    with pytest.raises(SvicpError):
+        ev.solve_end(1e-3, buf.data_ptr())
+    with pytest.raises(SvicpError):
+        ev.solve_begin(-1.0, buf.data_ptr())
+    with pytest.raises(SvicpError):
+        ev.solve_begin(1e-3, 0)
+    ev.solve_begin(1e-3, buf.data_ptr())
+    with pytest.raises(SvicpError):
+        ev.solve_end(1e-3, 0)
+    step, ps, pv = ev.solve_end(1e-3, buf.data_ptr())
+    want, wpred = ev.solve_damped(1e-3)
+    assert np.array_equal(step, want) and ps + pv == wpred     # one context: the same kernels, the same sums
+    with pytest.raises(SvicpError):
+        ev.solve_end(1e-3, buf.data_ptr())                      # consumed: begin again first
     ev.close()
 
 
