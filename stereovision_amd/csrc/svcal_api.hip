@@ -304,8 +304,8 @@ int solve_first_half(svcal_ctx *ctx, double lam, const char *who)
                        ctx->gram_view, V, nI, lam, ctx->sv_W, ctx->sv_contrib, ctx->sv_flags);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, who, e);
-    hipLaunchKernelGGL(cal_contrib_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->sv_contrib, V, nI,
-                       ctx->sv_csum);
+    hipLaunchKernelGGL(cal_contrib_sum_kernel, dim3(kSolveSums), dim3(256), 0, ctx->stream, ctx->sv_contrib,
+                       V, nI, ctx->sv_csum);
     e = hipGetLastError();
     if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, who, e);
     return SVICP_OK;

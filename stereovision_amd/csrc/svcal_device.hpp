@@ -231,21 +231,31 @@ __global__ __launch_bounds__(kThreads) void cal_eval_kernel(
     }
 }
 
-// Sums the per-view Gram matrices over the views: out[camera][136].
-__global__ __launch_bounds__(256) void cal_reduce_kernel(const double *__restrict__ gram_view, int V,
-                                                         double *__restrict__ gram_sum)
+// Column sums of a table of `rows` rows (row stride `stride` doubles): block e adds up
+// column e, thread t the rows t, t + 256, ..., then a tree over the threads, so the result is
+// the same bits on every run.  Columns from `columns` on (blocks past it) are set to zero.
+__device__ __forceinline__ void column_sum(const double *__restrict__ table, int rows, int stride,
+                                           int columns, double *__restrict__ out)
 {
     __shared__ double red[256];
-    const int task = blockIdx.x;           // camera * 136 + entry
+    const int e = blockIdx.x;
     double s = 0.0;
-    for (int v = threadIdx.x; v < V; v += 256) s += gram_view[(size_t)v * 2 * kGram + task];
+    if (e < columns)
+        for (int r = threadIdx.x; r < rows; r += 256) s += table[(size_t)r * stride + e];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
         if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) gram_sum[task] = red[0];
+    if (threadIdx.x == 0) out[e] = red[0];
+}
+
+// Sums the per-view Gram matrices over the views: out[camera][136].
+__global__ __launch_bounds__(256) void cal_reduce_kernel(const double *__restrict__ gram_view, int V,
+                                                         double *__restrict__ gram_sum)
+{
+    column_sum(gram_view, V, 2 * kGram, gridDim.x, gram_sum);   // block = camera * 136 + entry
 }
 
 // doImageRectify (CStereoCameraRectification.cpp:60-143): one thread per pixel of the
@@ -386,26 +396,15 @@ __global__ void cal_view_eliminate_kernel(const double *__restrict__ gram_view, 
 
 constexpr int kSolveSums = 9 * 10;   // a view's contribution: nI x (nI + 1) doubles, nI <= 9
 
-// One block.  The views' contributions summed in a fixed order into csum[0 .. kSolveSums)
-// (entries past nI (nI + 1): zero).  With the views split over several devices this is the
-// part of the shared system that has to be added up across them before it is solved.
+// The views' contributions summed in a fixed order into csum[0 .. kSolveSums) (entries past
+// nI (nI + 1): zero), one block per entry.  With the views split over several devices this is
+// the part of the shared system that has to be added up across them before it is solved.
 __global__ __launch_bounds__(256) void cal_contrib_sum_kernel(const double *__restrict__ contrib,
                                                               int V, int nI,
                                                               double *__restrict__ csum)
 {
-    __shared__ double part[256];
     const int ne = nI * (nI + 1);
-    const int t = threadIdx.x;
-    // entry e by threads e and e + 128, half of the views each
-    const int e = t & 127, half = t >> 7;
-    double s = 0.0;
-    if (e < ne) {
-        const int v0 = half ? V / 2 : 0, v1 = half ? V : V / 2;
-        for (int v = v0; v < v1; ++v) s += contrib[(size_t)v * ne + e];
-    }
-    part[t] = s;
-    __syncthreads();
-    if (t < kSolveSums) csum[t] = t < ne ? part[t] + part[t + 128] : 0.0;
+    column_sum(contrib, V, ne, ne, csum);
 }
 
 // One block.  Assembles the damped shared system from the summed triangles and the summed
