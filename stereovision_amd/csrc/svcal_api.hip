@@ -26,6 +26,7 @@ struct svcal_ctx {
     // the damped solve: per-view solutions and contributions, shared step, whole step, flags
     double *sv_W = nullptr, *sv_contrib = nullptr, *sv_dc = nullptr, *sv_step = nullptr, *sv_pred = nullptr;
     double *sv_csum = nullptr;       // the views' summed contribution to the shared system
+    double *h_step = nullptr;        // pinned: the step and its tail as they come off the device
     int *sv_flags = nullptr;
     int sv_views = 0;
     bool solve_begun = false;        // svcal_solve_begin ran for the blocks now on the device
@@ -78,6 +79,8 @@ void free_obs(svcal_ctx *ctx)
     ctx->sv_flags = nullptr;
     ctx->sv_views = 0;
     ctx->solve_begun = false;
+    if (ctx->h_step) (void)hipHostFree(ctx->h_step);
+    ctx->h_step = nullptr;
 }
 
 int param_count(const svcal_ctx *ctx, int k)
@@ -281,7 +284,10 @@ int ensure_solve_buffers(svcal_ctx *ctx)
     CHK(hipMalloc((void **)&ctx->sv_W, sizeof(double) * (size_t)V * 6 * 10));
     CHK(hipMalloc((void **)&ctx->sv_contrib, sizeof(double) * (size_t)V * 9 * 10));
     CHK(hipMalloc((void **)&ctx->sv_dc, sizeof(double) * (kMaxShared + 1)));
-    CHK(hipMalloc((void **)&ctx->sv_step, sizeof(double) * (2 * 9 + 6 * (size_t)V + 6)));
+    CHK(hipMalloc((void **)&ctx->sv_step, sizeof(double) * (2 * 9 + 6 * (size_t)V + 6 + 3)));
+    if (ctx->h_step) CHK(hipHostFree(ctx->h_step));
+    ctx->h_step = nullptr;
+    CHK(hipHostMalloc((void **)&ctx->h_step, sizeof(double) * (2 * 9 + 6 * (size_t)V + 6 + 3), 0));
     CHK(hipMalloc((void **)&ctx->sv_pred, sizeof(double) * (size_t)V));
     CHK(hipMalloc((void **)&ctx->sv_flags, sizeof(int)));
     CHK(hipMalloc((void **)&ctx->sv_csum, sizeof(double) * kSolveSums));
@@ -325,22 +331,21 @@ int solve_second_half(svcal_ctx *ctx, double lam, double *step_out, double predi
                        ctx->sv_W, ctx->sv_dc, V, nI, ctx->stereo, lam, ctx->sv_step, ctx->sv_pred);
     e = hipGetLastError();
     if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, who, e);
-    std::vector<double> pv(V);
-    double shared_pred = 0.0;
-    int flags = 0;
-    CHK(hipMemcpyAsync(step_out, ctx->sv_step, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
-    CHK(hipMemcpyAsync(pv.data(), ctx->sv_pred, sizeof(double) * V, hipMemcpyDeviceToHost, ctx->stream));
-    CHK(hipMemcpyAsync(&shared_pred, ctx->sv_dc + kMaxShared, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CHK(hipMemcpyAsync(&flags, ctx->sv_flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(cal_step_tail_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->sv_pred, V, ctx->sv_dc,
+                       ctx->sv_flags, ctx->sv_step + P);
+    e = hipGetLastError();
+    if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, who, e);
+    // one copy into pinned memory: the step, then the two parts of the prediction and the flags
+    CHK(hipMemcpyAsync(ctx->h_step, ctx->sv_step, sizeof(double) * (P + 3), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
+    const int flags = (int)ctx->h_step[P + 2];
     if (flags)
         return cfail(ctx, SVICP_ERR_SINGULAR,
                      flags & 2 ? "svcal_solve: the shared system is not positive definite"
                                : "svcal_solve: a view's 6 x 6 block is not positive definite");
-    double s = 0.0;
-    for (int v = 0; v < V; ++v) s += pv[v];              // in view order, always
-    predicted[0] = shared_pred;
-    predicted[1] = s;
+    std::memcpy(step_out, ctx->h_step, sizeof(double) * P);
+    predicted[0] = ctx->h_step[P];
+    predicted[1] = ctx->h_step[P + 1];
     return SVICP_OK;
 }
 }  // namespace

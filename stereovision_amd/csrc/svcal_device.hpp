@@ -505,4 +505,16 @@ __global__ void cal_view_step_kernel(const double *__restrict__ gram_view, const
     pred_view[v] = pred;
 }
 
+// One block, after cal_view_step_kernel: what the host reads besides the step, behind it in
+// the same buffer (one copy): tail[0] = the shared parameters' part of step^T (lam step - G),
+// tail[1] = the views' part, summed in a fixed order, tail[2] = the flags.
+__global__ __launch_bounds__(256) void cal_step_tail_kernel(const double *__restrict__ pred_view, int V,
+                                                            const double *__restrict__ dc,
+                                                            const int *__restrict__ flags,
+                                                            double *__restrict__ tail)
+{
+    column_sum(pred_view, V, 1, 1, tail + 1);
+    if (threadIdx.x == 0) { tail[0] = dc[kMaxShared]; tail[2] = (double)*flags; }
+}
+
 }  // namespace svcal
