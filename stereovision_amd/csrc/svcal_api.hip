@@ -27,6 +27,8 @@ struct svcal_ctx {
     double *sv_W = nullptr, *sv_contrib = nullptr, *sv_dc = nullptr, *sv_step = nullptr, *sv_pred = nullptr;
     double *sv_csum = nullptr;       // the views' summed contribution to the shared system
     double *h_step = nullptr;        // pinned: the step and its tail as they come off the device
+    double *h_params = nullptr;      // pinned: the parameter vector on its way to the device
+    double *h_small = nullptr;       // pinned: a few doubles on their way back (|e|^2)
     int *sv_flags = nullptr;
     int sv_views = 0;
     bool solve_begun = false;        // svcal_solve_begin ran for the blocks now on the device
@@ -128,6 +130,8 @@ int svcal_destroy(svcal_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_obs(ctx);
     if (ctx->params) (void)hipFree(ctx->params);
+    if (ctx->h_params) (void)hipHostFree(ctx->h_params);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SVICP_OK;
@@ -174,14 +178,20 @@ int svcal_set_params(svcal_ctx *ctx, const double *params, int k_size)
     CHK(hipSetDevice(ctx->device));
     const size_t bytes = sizeof(double) * (size_t)param_count(ctx, k_size);
     if (bytes > ctx->cap_params) {
+        CHK(hipStreamSynchronize(ctx->stream));
         if (ctx->params) CHK(hipFree(ctx->params));
-        ctx->params = nullptr; ctx->cap_params = 0;
+        if (ctx->h_params) CHK(hipHostFree(ctx->h_params));
+        ctx->params = ctx->h_params = nullptr; ctx->cap_params = 0;
         CHK(hipMalloc((void **)&ctx->params, bytes));
+        CHK(hipHostMalloc((void **)&ctx->h_params, bytes, 0));
         ctx->cap_params = bytes;
     }
     ctx->k = k_size;
-    CHK(hipMemcpyAsync(ctx->params, params, bytes, hipMemcpyHostToDevice, ctx->stream));
-    CHK(hipStreamSynchronize(ctx->stream));   // the caller may reuse its buffer
+    // through the context's own pinned buffer: the caller may reuse its vector at once, and
+    // the copy to the device need not be waited for (a copy from pageable memory would be)
+    CHK(hipStreamSynchronize(ctx->stream));   // the last upload has left the pinned buffer
+    std::memcpy(ctx->h_params, params, bytes);
+    CHK(hipMemcpyAsync(ctx->params, ctx->h_params, bytes, hipMemcpyHostToDevice, ctx->stream));
     ctx->have_params = true;
     return SVICP_OK;
 }
@@ -260,7 +270,9 @@ int svcal_sq_residual(svcal_ctx *ctx, double *out)
     if (!ctx || !out) return cfail(ctx, SVICP_ERR_ARG, "svcal_sq_residual: NULL argument");
     if (!ctx->evaluated) return cfail(ctx, SVICP_ERR_ARG, "svcal_sq_residual: nothing evaluated yet");
     CHK(hipSetDevice(ctx->device));
-    double e2[2] = { 0.0, 0.0 };                         // entry (15, 15) of each summed triangle
+    if (!ctx->h_small) CHK(hipHostMalloc((void **)&ctx->h_small, sizeof(double) * 4, 0));
+    double *e2 = ctx->h_small;                           // entry (15, 15) of each summed triangle
+    e2[0] = e2[1] = 0.0;
     CHK(hipMemcpyAsync(&e2[0], ctx->gram_sum + kGram - 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->stereo)
         CHK(hipMemcpyAsync(&e2[1], ctx->gram_sum + 2 * kGram - 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
