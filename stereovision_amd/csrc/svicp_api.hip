@@ -81,6 +81,7 @@ struct svicp_ctx {
     DevBuf partials, totals, deltas, state, xhist, ihist;
     IcpState *h_state = nullptr;   // pinned and mapped: the kernel that ends a run writes it
     IcpState *h_state_dev = nullptr;
+    float *h_small = nullptr;      // pinned: small results on their way back (bounding box, counts)
     int hist_cap = 0, last_iters = 0;
     int nb = 0, chunk = 0;
     hipGraphExec_t gexec = nullptr;
@@ -151,6 +152,15 @@ void drop_graph(svicp_ctx *ctx)
     ctx->g_iters_p2p = -1;
 }
 
+// A pinned page for results of a few bytes: a copy into pageable memory costs tens of
+// microseconds more.
+constexpr size_t kSmallBytes = 8192;
+int ensure_small(svicp_ctx *ctx)
+{
+    if (!ctx->h_small) HIPCHK(hipHostMalloc((void **)&ctx->h_small, kSmallBytes, 0));
+    return SVICP_OK;
+}
+
 // bounding box of an n x 3 device array; returns through mn/mx
 int device_bbox(svicp_ctx *ctx, const float *aos, int64_t n, float mn[3], float mx[3])
 {
@@ -159,9 +169,10 @@ int device_bbox(svicp_ctx *ctx, const float *aos, int64_t n, float mn[3], float 
     hipLaunchKernelGGL(bbox_kernel, dim3(nblk), dim3(kBlockThreads), 0, ctx->stream, aos,
                        (long long)n, ctx->bbox6.as<float>());
     LAUNCHCHK("bbox_kernel");
-    std::vector<float> h(6 * nblk);
-    HIPCHK(hipMemcpyAsync(h.data(), ctx->bbox6.p, sizeof(float) * 6 * nblk, hipMemcpyDeviceToHost,
-                          ctx->stream));
+    int rc = ensure_small(ctx);
+    if (rc) return rc;
+    float *h = ctx->h_small;
+    HIPCHK(hipMemcpyAsync(h, ctx->bbox6.p, sizeof(float) * 6 * nblk, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int a = 0; a < 3; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
     for (int b = 0; b < nblk; ++b)
@@ -449,6 +460,7 @@ int svicp_destroy(svicp_ctx *ctx)
                        &ctx->ihist, &ctx->p2p_sums, &ctx->rthist };
     for (DevBuf *b : bufs) b->release();
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SVICP_OK;
@@ -598,13 +610,15 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
         HIPCHK(rocprim::exclusive_scan(ctx->sort_tmp.p, bytes, ctx->marks.as<int>(),
                                        ctx->ranks.as<int>(), 0, (size_t)nbt, rocprim::plus<int>(),
                                        ctx->stream));
-        int last_rank = 0, last_mark = 0;
-        HIPCHK(hipMemcpyAsync(&last_rank, ctx->ranks.as<int>() + (nbt - 1), sizeof(int),
+        int rc = ensure_small(ctx);
+        if (rc) return rc;
+        int *last = reinterpret_cast<int *>(ctx->h_small);     // {last rank, last mark}
+        HIPCHK(hipMemcpyAsync(&last[0], ctx->ranks.as<int>() + (nbt - 1), sizeof(int),
                               hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(&last_mark, ctx->marks.as<int>() + (nbt - 1), sizeof(int),
+        HIPCHK(hipMemcpyAsync(&last[1], ctx->marks.as<int>() + (nbt - 1), sizeof(int),
                               hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        nranked = last_rank + last_mark;
+        nranked = last[0] + last[1];
     }
     ctx->nranked = nranked;
     hipLaunchKernelGGL(finish_dir_kernel, dim3(cdiv(nbt, 256)), dim3(256), 0, ctx->stream,
