@@ -436,42 +436,47 @@ __global__ __launch_bounds__(256) void cal_shared_solve_kernel(
     for (int r = t; r < nC; r += 256)
         S[r][kMaxShared] = r < nI ? GL[tri_at(r, 15)] - csum[r * nc + nI] : GR[tri_at(r - nI, 15)];
     __syncthreads();
-    // ---- Cholesky, column by column; thread r owns row r ----
+    // ---- Cholesky, column by column, the rest of the matrix updated as each column is done
+    // (every entry of the rest by its own thread, one barrier per column) and the gradient
+    // carried along as one more row, so that L y = g is solved on the way.  Column c is
+    // scaled while column c + 1 is at work: the two touch different entries. ----
+    __shared__ double x[kMaxShared], term[kMaxShared];
+    constexpr int G = kMaxShared;
     for (int c = 0; c < nC; ++c) {
-        if (t == c) {
-            double d = S[c][c];
-            for (int k = 0; k < c; ++k) d -= S[c][k] * S[c][k];
-            if (!(d > 0.0)) { atomicOr(flags, 2); d = 1.0; }
-            S[c][c] = sqrt(d);
+        const double d = S[c][c];
+        if (!(d > 0.0) && t == 0) atomicOr(flags, 2);
+        const double inv_d = d > 0.0 ? 1.0 / d : 1.0, r = sqrt(inv_d);
+        const double gc = S[c][G];
+        double col_t = 0.0;
+        if (t > c && t < nC) col_t = S[t][c];
+        for (int e = t; e < kMaxShared * kMaxShared; e += 256) {
+            const int i = c + 1 + e / kMaxShared, j = c + 1 + e % kMaxShared;
+            if (j <= i && i < nC) S[i][j] -= S[i][c] * S[j][c] * inv_d;
         }
+        if (t > c && t < nC) S[t][G] -= col_t * gc * inv_d;
         __syncthreads();
-        if (t > c && t < nC) {
-            double s = S[t][c];
-            for (int k = 0; k < c; ++k) s -= S[t][k] * S[c][k];
-            S[t][c] = s / S[c][c];
-        }
+        if (t > c && t < nC) S[t][c] = col_t * r;              // L[t][c]
+        if (t == c) { S[c][c] = r; S[c][G] = gc * r; }         // 1 / L[c][c], y[c]
+    }
+    __syncthreads();
+    // ---- L^T x = y, from the last row up ----
+    for (int rr = nC - 1; rr >= 0; --rr) {
+        const double xr = S[rr][G] * S[rr][rr];
+        if (t < rr) S[t][G] -= S[rr][t] * xr;
+        if (t == rr) x[rr] = xr;
         __syncthreads();
     }
+    // the gradient of the shared parameters as the caller knows it (before elimination)
+    if (t < nC) {
+        const double g = t < nI ? GL[tri_at(t, 15)] : GR[tri_at(t - nI, 15)];
+        const double d = -x[t];
+        dc_out[t] = d;
+        term[t] = d * (lam * d - g);
+    }
+    __syncthreads();
     if (t == 0) {
-        double x[kMaxShared];
-        for (int r = 0; r < nC; ++r) {
-            double s = S[r][kMaxShared];
-            for (int k = 0; k < r; ++k) s -= S[r][k] * x[k];
-            x[r] = s / S[r][r];
-        }
-        for (int r = nC - 1; r >= 0; --r) {
-            double s = x[r];
-            for (int k = r + 1; k < nC; ++k) s -= S[k][r] * x[k];
-            x[r] = s / S[r][r];
-        }
-        // the gradient of the shared parameters as the caller knows it (before elimination)
         double pred = 0.0;
-        for (int r = 0; r < nC; ++r) {
-            const double g = r < nI ? GL[tri_at(r, 15)] : GR[tri_at(r - nI, 15)];
-            const double d = -x[r];
-            dc_out[r] = d;
-            pred += d * (lam * d - g);
-        }
+        for (int rr = 0; rr < nC; ++rr) pred += term[rr];
         dc_out[kMaxShared] = pred;
     }
 }
