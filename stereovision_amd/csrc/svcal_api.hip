@@ -318,7 +318,7 @@ int solve_first_half(svcal_ctx *ctx, double lam, const char *who)
     if (rc) return rc;
     const int V = ctx->V, nI = 4 + ctx->k;
     CHK(hipMemsetAsync(ctx->sv_flags, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(cal_view_eliminate_kernel, dim3((V + 63) / 64), dim3(64), 0, ctx->stream,
+    hipLaunchKernelGGL(cal_view_eliminate_kernel, dim3((V * (nI + 1) + 63) / 64), dim3(64), 0, ctx->stream,
                        ctx->gram_view, V, nI, lam, ctx->sv_W, ctx->sv_contrib, ctx->sv_flags);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, who, e);

@@ -331,14 +331,18 @@ __device__ __forceinline__ int tri_at(int a, int b)
     return lo * 16 - (lo * (lo - 1)) / 2 + (hi - lo);
 }
 
-// One thread per view.  W[v] = (EE + lam diag EE)^-1 [LE^T | gE]   (6 x (nI + 1), kept for the
+// W[v] = (EE + lam diag EE)^-1 [LE^T | gE]   (6 x (nI + 1), kept for the
 // last kernel) and contrib[v] = LE W[v]   (nI x (nI + 1): what the view takes out of the shared
 // system).  flags[0] is set when a block is not positive definite.
 __global__ void cal_view_eliminate_kernel(const double *__restrict__ gram_view, int V, int nI,
                                           double lam, double *__restrict__ W,
                                           double *__restrict__ contrib, int *__restrict__ flags)
 {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    // one thread per (view, column of [LE^T | gE]): the 6 x 6 factorisation is short, and
+    // repeated by the nI + 1 threads of a view it keeps ten times as many lanes busy
+    const int nc = nI + 1;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = gid / nc, c = gid - v * nc;
     if (v >= V) return;
     const double *G = gram_view + (size_t)v * 2 * kGram;       // the left camera's triangle
     double L[6][6];
@@ -363,9 +367,8 @@ __global__ void cal_view_eliminate_kernel(const double *__restrict__ gram_view, 
             L[q][c] = s * r;
         }
     }
-    if (!ok) atomicOr(flags, 1);
-    const int nc = nI + 1;
-    for (int c = 0; c < nc; ++c) {                             // column c of [LE^T | gE]
+    if (!ok && c == 0) atomicOr(flags, 1);
+    {                                                          // column c of [LE^T | gE]
         double x[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) x[q] = G[tri_at(c < nI ? c : nI + q, c < nI ? nI + q : 15)];
