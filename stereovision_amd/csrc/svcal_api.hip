@@ -32,6 +32,8 @@ struct svcal_ctx {
     int *sv_flags = nullptr;
     int sv_views = 0;
     bool solve_begun = false;        // svcal_solve_begin ran for the blocks now on the device
+    double begun_lam = 0.0;          // the damping svcal_solve_begin was given
+    bool imported = false;           // gram_sum holds sums over ALL ranks' views (svcal_shard_import)
 };
 
 namespace {
@@ -217,6 +219,7 @@ int svcal_eval(svcal_ctx *ctx)
     if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, "cal_reduce_kernel", e);
     ctx->evaluated = true;
     ctx->solve_begun = false;
+    ctx->imported = false;
     return SVICP_OK;
 }
 
@@ -365,6 +368,10 @@ int solve_second_half(svcal_ctx *ctx, double lam, double *step_out, double predi
 int svcal_solve_damped(svcal_ctx *ctx, double lam, double *step_out, double *predicted_out)
 {
     if (!ctx || !step_out) return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_damped: NULL argument");
+    if (ctx->imported)
+        return cfail(ctx, SVICP_ERR_ARG,
+                     "svcal_solve_damped: the shared sums cover every rank's views (svcal_shard_import) but "
+                     "only this rank's views are here; use svcal_solve_begin / svcal_solve_end");
     int rc = solve_first_half(ctx, lam, "svcal_solve_damped");
     if (rc) return rc;
     double pred[2];
@@ -382,6 +389,7 @@ int svcal_solve_begin(svcal_ctx *ctx, double lam, double *dev_sums90)
     CHK(hipMemcpyAsync(dev_sums90, ctx->sv_csum, sizeof(double) * kSolveSums, hipMemcpyDeviceToDevice,
                        ctx->stream));
     ctx->solve_begun = true;
+    ctx->begun_lam = lam;
     return SVICP_OK;
 }
 
@@ -393,6 +401,8 @@ int svcal_solve_end(svcal_ctx *ctx, double lam, const double *dev_sums90, double
     if (!ctx->solve_begun) return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_end: call svcal_solve_begin first");
     if (!(lam >= 0.0) || !std::isfinite(lam))
         return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_end: the damping must be finite and >= 0");
+    if (lam != ctx->begun_lam)
+        return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_end: the damping differs from svcal_solve_begin's");
     CHK(hipSetDevice(ctx->device));
     ctx->solve_begun = false;
     CHK(hipMemcpyAsync(ctx->sv_csum, dev_sums90, sizeof(double) * kSolveSums, hipMemcpyDeviceToDevice,
@@ -426,6 +436,7 @@ int svcal_shard_import(svcal_ctx *ctx, const double *dev_sums272)
     CHK(hipSetDevice(ctx->device));
     CHK(hipMemcpyAsync(ctx->gram_sum, dev_sums272, sizeof(double) * 2 * kGram, hipMemcpyDeviceToDevice,
                        ctx->stream));
+    ctx->imported = true;
     return SVICP_OK;
 }
 

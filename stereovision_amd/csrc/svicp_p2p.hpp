@@ -41,9 +41,10 @@ __device__ __forceinline__ void block_atomic_add(double (&v)[NV], double *out, d
 // was not selected (no neighbour with d2 < threshold).
 template <bool APPLY>
 __global__ __launch_bounds__(256, 4) void p2p_match_kernel(
-    GridDesc g, const float *__restrict__ sx_in, const float *__restrict__ sy_in,
-    const float *__restrict__ sz_in, float *__restrict__ sx_out, float *__restrict__ sy_out,
-    float *__restrict__ sz_out, int n, const IcpState *__restrict__ st, float thr,
+    // the coordinate arrays carry no __restrict__: from the third iteration on the points are
+    // updated where they are read (s?_in == s?_out)
+    GridDesc g, const float *sx_in, const float *sy_in, const float *sz_in, float *sx_out,
+    float *sy_out, float *sz_out, int n, const IcpState *__restrict__ st, float thr,
     float4 *__restrict__ tp, double *__restrict__ sums)
 {
     __shared__ double red[4][32];
