@@ -116,10 +116,33 @@ int svicp_get_source(svicp_ctx *ctx, float *xyz_aos_out);
  * All iterations run on the device without a host round trip. */
 int svicp_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info);
 
+/* svicp_run for callers that cannot allocate device memory or wait on the device
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  It has no counterpart in the reference.  The same kernels as
+ * svicp_run, launched one by one on the context's stream; nothing is allocated,
+ * freed, instantiated or synchronised: the sums, the iteration state and the
+ * history live in a file-scope device array of about 1.2 MB that every context on
+ * that device shares and that keeps the last call's contents (what must start at
+ * zero is cleared by the call).  Two such calls that overlap on one GPU (different
+ * streams, or contexts used by different threads) race; calls on one stream do not.
+ * Limits, rejected with SVICP_ERR_ARG: iterations <= 128, source <= 4194304 points.
+ * The clouds are the resident ones (svicp_set_target / svicp_set_source allocate;
+ * call them beforehand).  dev_out20: DEVICE memory, 20 doubles, written by the last
+ * kernel: the accumulated 4x4 transform row-major, then {status (SVICP_OK or
+ * SVICP_ERR_SINGULAR), inliers, sum w b^2, |X|} of the last iteration.  The call
+ * returns once the work is queued; svicp_get_history afterwards reports "no run". */
+int svicp_run_enqueue(svicp_ctx *ctx, int iterations, double *dev_out20);
+
+/* Iterations of the last successful run on this context (svicp_run,
+ * svicp_run_point2point, svicp_batch_run, svicp_shard_update): the number of rows
+ * the history calls below copy.  0 before any run. */
+int svicp_last_iterations(const svicp_ctx *ctx, int *iterations);
+
 /* Per-iteration record of the last svicp_run: X_out iterations x 6 (the
  * solution vector X of CPoint2PlaneICP.cpp:109), info_out iterations x 4
- * {inliers, sum w b^2, |X|, sum w}.  Either may be NULL. */
-int svicp_get_history(svicp_ctx *ctx, double *X_out, double *info_out);
+ * {inliers, sum w b^2, |X|, sum w}.  Either may be NULL.  capacity_rows: rows the
+ * caller's arrays hold; SVICP_ERR_ARG when fewer than svicp_last_iterations. */
+int svicp_get_history(svicp_ctx *ctx, int capacity_rows, double *X_out, double *info_out);
 
 /* 1-NN correspondences of the current source against the target, as used by
  * the last solve (CPoint2PlaneICP.cpp:65-67).  idx_out, d2_out: n entries,
@@ -155,6 +178,10 @@ int svicp_knn(svicp_ctx *ctx, const float *query_aos, int64_t n, int k,
  * non-blocking stream (the initial state). */
 int svicp_set_stream(svicp_ctx *ctx, void *hip_stream);
 int svicp_use_own_stream(svicp_ctx *ctx);
+
+/* Waits until everything queued on the context's stream has completed (what a
+ * caller of svicp_run_enqueue does before it reads dev_out20 from the host). */
+int svicp_synchronize(svicp_ctx *ctx);
 
 /* Resets the accumulated transform and the iteration counter. */
 int svicp_shard_begin(svicp_ctx *ctx);
@@ -192,8 +219,9 @@ int svicp_run_point2point(svicp_ctx *ctx, int iterations, double T_out[16], svic
 
 /* Per-iteration increments of the last svicp_run_point2point: RT_out
  * iterations x 12 {R row-major, T}; info_out iterations x 4 {selected count,
- * sum w d^2, step norm, sum w}.  Either pointer may be NULL. */
-int svicp_get_history_rt(svicp_ctx *ctx, double *RT_out, double *info_out);
+ * sum w d^2, step norm, sum w}.  Either pointer may be NULL; capacity_rows as for
+ * svicp_get_history. */
+int svicp_get_history_rt(svicp_ctx *ctx, int capacity_rows, double *RT_out, double *info_out);
 
 /* ---- batches of independent pairs (one launch per iteration for all) ---- */
 /* Many small registrations do not fill the GPU one at a time.  A batch takes
@@ -228,9 +256,10 @@ int svicp_batch_last_ms(const svicp_batch *batch, double *ms);
 int svicp_kernel_times(svicp_ctx *ctx, double *fused_ms, double *solve_ms, int *launches);
 
 /* Number of source points that went through the neighbour search in each
- * iteration of the last svicp_run (`iterations` entries); the others kept
- * their correspondence by the proof described at options.coherent. */
-int svicp_search_counts(svicp_ctx *ctx, double *counts_out);
+ * iteration of the last svicp_run (`iterations` entries; capacity_rows as for
+ * svicp_get_history); the others kept their correspondence by the proof described
+ * at options.coherent. */
+int svicp_search_counts(svicp_ctx *ctx, int capacity_rows, double *counts_out);
 
 /* The same two quantities per iteration over the last timed svicp_run:
  * `iterations` entries each.  Either pointer may be NULL. */

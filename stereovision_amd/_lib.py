@@ -57,11 +57,14 @@ SYMBOLS = {
     "svicp_set_source": (C.c_int, [_ctx, _fp, C.c_int64]),
     "svicp_get_source": (C.c_int, [_ctx, _fp]),
     "svicp_run": (C.c_int, [_ctx, C.c_int, _dp, C.POINTER(Info)]),
-    "svicp_get_history": (C.c_int, [_ctx, _dp, _dp]),
+    "svicp_run_enqueue": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
+    "svicp_last_iterations": (C.c_int, [_ctx, C.POINTER(C.c_int)]),
+    "svicp_get_history": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
     "svicp_correspondences": (C.c_int, [_ctx, _ip, _fp]),
     "svicp_knn": (C.c_int, [_ctx, _fp, C.c_int64, C.c_int, _ip, _fp]),
     "svicp_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "svicp_use_own_stream": (C.c_int, [_ctx]),
+    "svicp_synchronize": (C.c_int, [_ctx]),
     "svicp_shard_begin": (C.c_int, [_ctx]),
     "svicp_shard_accumulate": (C.c_int, [_ctx, C.c_void_p]),
     "svicp_shard_update": (C.c_int, [_ctx, C.c_void_p]),
@@ -70,9 +73,9 @@ SYMBOLS = {
     "svicp_iteration_times": (C.c_int, [_ctx, _dp, _dp]),
     "svicp_time_nn": (C.c_int, [_ctx, C.c_int, C.c_int, _dp]),
     "svicp_sizes": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    "svicp_search_counts": (C.c_int, [_ctx, _dp]),
+    "svicp_search_counts": (C.c_int, [_ctx, C.c_int, _dp]),
     "svicp_run_point2point": (C.c_int, [_ctx, C.c_int, _dp, C.POINTER(Info)]),
-    "svicp_get_history_rt": (C.c_int, [_ctx, _dp, _dp]),
+    "svicp_get_history_rt": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
     "svicp_batch_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.POINTER(C.c_void_p)]),
     "svicp_batch_destroy": (C.c_int, [C.c_void_p]),
     "svicp_batch_last_error": (C.c_char_p, [C.c_void_p]),

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,46 @@ struct ScopedEvent {
 
 }  // namespace
 
+// ---- the workspace of svicp_run_enqueue: one file-scope array per device ----
+// Everything the iteration loop needs beyond the resident clouds and their per-point state:
+// the tiles' sums, the running totals and their per-iteration changes, the iteration state and
+// history, the tiles' "had work" flags.  Sized for kEnqMaxIters iterations of a source of
+// kEnqMaxTiles tiles (1024 points each).
+constexpr int kEnqMaxIters = 128;
+constexpr int kEnqMaxTiles = 4096;
+constexpr size_t enq_align(size_t b) { return (b + 255) & ~(size_t)255; }
+constexpr size_t kEnqOffState = 0;
+constexpr size_t kEnqOffTotals = kEnqOffState + enq_align(sizeof(IcpState));
+constexpr size_t kEnqOffDeltas = kEnqOffTotals + enq_align(sizeof(double) * kNumSums * (kEnqMaxIters + 1));
+constexpr size_t kEnqOffXhist = kEnqOffDeltas + enq_align(sizeof(double) * kDeltaRow * (kEnqMaxIters + 1));
+constexpr size_t kEnqOffIhist = kEnqOffXhist + enq_align(sizeof(double) * 6 * kEnqMaxIters);
+constexpr size_t kEnqOffFlags = kEnqOffIhist + enq_align(sizeof(double) * 4 * kEnqMaxIters);
+constexpr size_t kEnqOffPartials = kEnqOffFlags + enq_align(2 * kFlagCap);
+constexpr size_t kEnqBytes = kEnqOffPartials + enq_align(sizeof(double) * kNumSums * kEnqMaxTiles);
+static __device__ __align__(256) unsigned char scratch[kEnqBytes];   // about 1.2 MB
+
+namespace {
+// Device address of `scratch` on each device (the array's name is a host-side stand-in, not
+// an address a kernel can use): asked for once per device, with that device current.
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices] = {};
+
+hipError_t scratch_on_current_device(int device, unsigned char **out)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = static_cast<unsigned char *>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+}  // namespace
+
 struct svicp_ctx {
     int device = 0;
     int num_cus = 256;
@@ -94,6 +135,7 @@ struct svicp_ctx {
     int timed_launches = 0;
 
     int shard_iter = 0;
+    unsigned char *enq_scratch = nullptr;   // this device's copy of `scratch`
 
     // point-to-point variant
     DevBuf p2p_sums, rthist;
@@ -114,6 +156,7 @@ struct svicp_batch {
     int iters_cap = 0;
     hipGraphExec_t gexec = nullptr;
     int g_iters = -1;
+    bool g_coherent = true;             // the option the captured graph was built with
     double last_ms = 0.0;
 };
 
@@ -288,14 +331,6 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
     const int nb = std::max(1, cdiv(std::max<int64_t>(n, 1), chunk));
     if (nb != ctx->nb || chunk != ctx->chunk) drop_graph(ctx);
     ctx->nb = nb; ctx->chunk = chunk;
-    {
-        DevBuf *bufs[] = { &ctx->st_tp, &ctx->st_nv };
-        for (DevBuf *b : bufs) {
-            void *before = b->p;
-            HIPCHK(b->reserve(sizeof(float4) * (size_t)std::max<int64_t>(n, 1)));
-            if (b->p != before) drop_graph(ctx);
-        }
-    }
     HIPCHK(ctx->partials.reserve(sizeof(double) * kNumSums * nb));
     if (!ctx->tile_flags.p) {
         HIPCHK(ctx->tile_flags.reserve(2 * kFlagCap));
@@ -322,8 +357,29 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
     return SVICP_OK;
 }
 
-// launches iteration k's kernel; the tile sums end up in `partials`
-void launch_iteration(svicp_ctx *ctx, int k, double *partials)
+// The small buffers of one iteration loop: the context's own, or (svicp_run_enqueue) places in
+// the device's file-scope workspace.
+struct LoopBufs {
+    double *partials, *totals, *deltas, *xhist, *ihist;
+    IcpState *state;
+    unsigned char *flags;    // [2][kFlagCap] or null
+};
+
+LoopBufs own_bufs(svicp_ctx *ctx)
+{
+    LoopBufs b;
+    b.partials = ctx->partials.as<double>();
+    b.totals = ctx->totals.as<double>();
+    b.deltas = ctx->deltas.as<double>();
+    b.xhist = ctx->xhist.as<double>();
+    b.ihist = ctx->ihist.as<double>();
+    b.state = ctx->state.as<IcpState>();
+    b.flags = ctx->nb <= kFlagCap ? ctx->tile_flags.as<unsigned char>() : nullptr;
+    return b;
+}
+
+// launches iteration k's kernel; the tile sums end up in `b.partials`
+void launch_iteration(svicp_ctx *ctx, int k, const LoopBufs &b)
 {
     const float thr = ctx->opt.dist_threshold;
     CohParams cp;
@@ -334,12 +390,13 @@ void launch_iteration(svicp_ctx *ctx, int k, double *partials)
     ps.tp = ctx->st_tp.as<Float3>();
     ps.nv = ctx->st_nv.as<Float3>();
     ps.lb = ctx->st_lb.as<float>();
-    ps.active = ctx->nb <= kFlagCap ? ctx->tile_flags.as<unsigned char>() : nullptr;
+    ps.active = b.flags;
     float *wx = ctx->wx.as<float>(), *wy = ctx->wy.as<float>(), *wz = ctx->wz.as<float>();
     const float *x0 = ctx->sx0.as<float>(), *y0 = ctx->sy0.as<float>(), *z0 = ctx->sz0.as<float>();
-    IcpState *state = ctx->state.as<IcpState>();
-    double *tot = ctx->totals.as<double>(), *del = ctx->deltas.as<double>();
-    double *xh = ctx->xhist.as<double>(), *ih = ctx->ihist.as<double>();
+    IcpState *state = b.state;
+    double *tot = b.totals, *del = b.deltas;
+    double *xh = b.xhist, *ih = b.ihist;
+    double *partials = b.partials;
     const dim3 grid(ctx->nb), block(kItThreads);
     const int n = (int)ctx->n;
 #define SVICP_ITERATE(APPLY, CERTIFY, INPLACE, ix, iy, iz)                                        \
@@ -356,14 +413,17 @@ void launch_iteration(svicp_ctx *ctx, int k, double *partials)
 #undef SVICP_ITERATE
 }
 
-int enqueue_loop(svicp_ctx *ctx, int iters, bool timed)
+// the whole loop on ctx->stream: `iters` iteration kernels and the solve that ends the run.
+// host_copy (mapped host memory) and dev_out (device, kRunOutDoubles doubles) may each be null.
+int enqueue_loop(svicp_ctx *ctx, int iters, bool timed, const LoopBufs &b, IcpState *host_copy,
+                 double *dev_out)
 {
     // no reset and no clearing here: the first solve of a run starts the state afresh,
     // totals row 0 is always zero, delta row k + 1 is cleared by iteration k's kernel and
     // row 0 by the solve kernel that ended the previous run
     for (int k = 0; k < iters; ++k) {
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 0], ctx->stream));
-        launch_iteration(ctx, k, ctx->partials.as<double>());
+        launch_iteration(ctx, k, b);
         LAUNCHCHK("icp_iterate_kernel");
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 1], ctx->stream));
         if (timed) HIPCHK(hipEventRecord(ctx->events[4 * k + 2], ctx->stream));
@@ -371,10 +431,8 @@ int enqueue_loop(svicp_ctx *ctx, int iters, bool timed)
     }
     // the last iteration's system is solved here; the others were solved at the
     // start of the following iteration's kernel
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->totals.as<double>(),
-                       ctx->deltas.as<double>(), ctx->state.as<IcpState>(),
-                       ctx->xhist.as<double>(), ctx->ihist.as<double>(), iters - 1,
-                       ctx->h_state_dev);
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, b.totals, b.deltas, b.state,
+                       b.xhist, b.ihist, iters - 1, host_copy, dev_out);
     LAUNCHCHK("solve_kernel");
     return SVICP_OK;
 }
@@ -440,6 +498,12 @@ int svicp_create(int device_id, svicp_ctx **out)
     e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, SVICP_ERR_HIP, "hipStreamCreate", e); }
     ctx->stream = ctx->own_stream;
+    e = scratch_on_current_device(device_id, &ctx->enq_scratch);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return fail(nullptr, SVICP_ERR_HIP, "hipGetSymbolAddress(scratch)", e);
+    }
     *out = ctx;
     return SVICP_OK;
 }
@@ -503,6 +567,14 @@ int svicp_set_stream(svicp_ctx *ctx, void *hip_stream)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;   // NULL is the default stream
     drop_graph(ctx);
+    return SVICP_OK;
+}
+
+int svicp_synchronize(svicp_ctx *ctx)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return SVICP_OK;
 }
 
@@ -709,6 +781,14 @@ int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n)
         HIPCHK(b->reserve(sizeof(float) * nn));
         if (b->p != before) drop_graph(ctx);
     }
+    {
+        // what the loop remembers per point: the matched target point (16 bytes: the
+        // point-to-point variant keeps the weight in the fourth word) and its normal (12)
+        void *before_tp = ctx->st_tp.p, *before_nv = ctx->st_nv.p;
+        HIPCHK(ctx->st_tp.reserve(sizeof(float4) * nn));
+        HIPCHK(ctx->st_nv.reserve(sizeof(Float3) * nn));
+        if (ctx->st_tp.p != before_tp || ctx->st_nv.p != before_nv) drop_graph(ctx);
+    }
     HIPCHK(ctx->tmp_aos.reserve(sizeof(float) * 3 * nn));
     ctx->n = n;
     ctx->cur = 0;
@@ -793,12 +873,13 @@ int svicp_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info
             ctx->events.push_back(ev);
         }
     }
-    if (ctx->opt.use_graph && !timed) {
+    // (the legacy default stream, svicp_set_stream(ctx, NULL), cannot be captured: eager there)
+    if (ctx->opt.use_graph && !timed && ctx->stream != nullptr) {
         if (!ctx->gexec || ctx->g_iters != iterations) {
             drop_graph(ctx);
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_loop(ctx, iterations, false);
+            rc = enqueue_loop(ctx, iterations, false, own_bufs(ctx), ctx->h_state_dev, nullptr);
             hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
             if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             if (e != hipSuccess) return fail(ctx, SVICP_ERR_HIP, "hipStreamEndCapture", e);
@@ -809,7 +890,7 @@ int svicp_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info
         }
         HIPCHK(hipGraphLaunch(ctx->gexec, ctx->stream));
     } else {
-        rc = enqueue_loop(ctx, iterations, timed);
+        rc = enqueue_loop(ctx, iterations, timed, own_bufs(ctx), ctx->h_state_dev, nullptr);
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));   // the last kernel wrote h_state
@@ -841,10 +922,58 @@ int svicp_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info
     return SVICP_OK;
 }
 
-int svicp_get_history(svicp_ctx *ctx, double *X_out, double *info_out)
+int svicp_run_enqueue(svicp_ctx *ctx, int iterations, double *dev_out20)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (!dev_out20) return fail(ctx, SVICP_ERR_ARG, "svicp_run_enqueue: dev_out20 is NULL");
+    if (iterations < 1 || iterations > kEnqMaxIters)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_run_enqueue: iterations must be in [1, 128]");
+    if (!ctx->have_target || !ctx->have_source)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_run_enqueue: set the target and the source first");
+    const int nb = std::max(1, cdiv(std::max<int64_t>(ctx->n, 1), kItTile));
+    if (nb > kEnqMaxTiles)
+        return fail(ctx, SVICP_ERR_ARG,
+                    "svicp_run_enqueue: the source exceeds the workspace (4194304 points at most)");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (nb != ctx->nb) drop_graph(ctx);     // (svicp_run's graph bakes the tile count in)
+    ctx->nb = nb; ctx->chunk = kItTile;
+    unsigned char *w = ctx->enq_scratch;    // the device address, never the array's name
+    LoopBufs b;
+    b.state = reinterpret_cast<IcpState *>(w + kEnqOffState);
+    b.totals = reinterpret_cast<double *>(w + kEnqOffTotals);
+    b.deltas = reinterpret_cast<double *>(w + kEnqOffDeltas);
+    b.xhist = reinterpret_cast<double *>(w + kEnqOffXhist);
+    b.ihist = reinterpret_cast<double *>(w + kEnqOffIhist);
+    b.flags = nb <= kFlagCap ? w + kEnqOffFlags : nullptr;
+    b.partials = reinterpret_cast<double *>(w + kEnqOffPartials);
+    // The array keeps the last call's contents.  What a run takes to be zero when it starts:
+    // row 0 of the totals and rows 0 and 1 of the per-iteration changes (every later row is
+    // cleared by the launch before the one that adds to it).  Everything else is written
+    // before it is read: the state by the first solve, the tiles' sums and flags by
+    // iteration 0.
+    HIPCHK(hipMemsetAsync(b.totals, 0, sizeof(double) * kNumSums, ctx->stream));
+    HIPCHK(hipMemsetAsync(b.deltas, 0, sizeof(double) * kDeltaRow * 2, ctx->stream));
+    int rc = enqueue_loop(ctx, iterations, false, b, nullptr, dev_out20);
+    if (rc) return rc;
+    ctx->cur = iterations > 1 ? 1 : 0;
+    ctx->last_iters = 0;                    // the history stays in the workspace
+    ctx->last_was_p2p = false;
+    return SVICP_OK;
+}
+
+int svicp_last_iterations(const svicp_ctx *ctx, int *iterations)
+{
+    if (!ctx || !iterations) return SVICP_ERR_ARG;
+    *iterations = ctx->last_iters;
+    return SVICP_OK;
+}
+
+int svicp_get_history(svicp_ctx *ctx, int capacity_rows, double *X_out, double *info_out)
 {
     if (!ctx) return SVICP_ERR_ARG;
     if (ctx->last_iters <= 0) return fail(ctx, SVICP_ERR_ARG, "svicp_get_history: no run yet");
+    if (capacity_rows < ctx->last_iters)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_get_history: capacity_rows is below the last run's iterations");
     HIPCHK(hipSetDevice(ctx->device));
     if (X_out)
         HIPCHK(hipMemcpyAsync(X_out, ctx->xhist.p, sizeof(double) * 6 * ctx->last_iters,
@@ -856,11 +985,13 @@ int svicp_get_history(svicp_ctx *ctx, double *X_out, double *info_out)
     return SVICP_OK;
 }
 
-int svicp_search_counts(svicp_ctx *ctx, double *counts_out)
+int svicp_search_counts(svicp_ctx *ctx, int capacity_rows, double *counts_out)
 {
     if (!ctx || !counts_out) return fail(ctx, SVICP_ERR_ARG, "svicp_search_counts: NULL argument");
     if (ctx->last_iters <= 0 || ctx->last_was_p2p)
         return fail(ctx, SVICP_ERR_ARG, "svicp_search_counts: no point-to-plane run yet");
+    if (capacity_rows < ctx->last_iters)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_search_counts: capacity_rows is below the last run's iterations");
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<double> rows((size_t)kDeltaRow * ctx->last_iters);
     HIPCHK(hipMemcpyAsync(rows.data(), ctx->deltas.p, sizeof(double) * rows.size(),
@@ -946,7 +1077,7 @@ int svicp_shard_accumulate(svicp_ctx *ctx, double *dev_partial32)
     if (ctx->shard_iter >= ctx->hist_cap)
         return fail(ctx, SVICP_ERR_ARG, "svicp_shard_accumulate: too many iterations since svicp_shard_begin");
     const int k = ctx->shard_iter;
-    launch_iteration(ctx, k, ctx->partials.as<double>());
+    launch_iteration(ctx, k, own_bufs(ctx));
     LAUNCHCHK("icp_iterate_kernel");
     // this rank's change of the sums in iteration k
     hipLaunchKernelGGL(fold_delta_kernel, dim3(1), dim3(64), 0, ctx->stream,
@@ -978,7 +1109,7 @@ int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info)
     hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->totals.as<double>(),
                        ctx->deltas.as<double>(), ctx->state.as<IcpState>(),
                        ctx->xhist.as<double>(), ctx->ihist.as<double>(), ctx->shard_iter - 1,
-                       (IcpState *)nullptr);
+                       (IcpState *)nullptr, (double *)nullptr);
     LAUNCHCHK("solve_kernel");
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->state.p, sizeof(IcpState), hipMemcpyDeviceToHost,
                           ctx->stream));
@@ -1098,7 +1229,7 @@ int svicp_run_point2point(svicp_ctx *ctx, int iterations, double T_out[16], svic
         }
         return SVICP_OK;
     };
-    if (ctx->opt.use_graph) {
+    if (ctx->opt.use_graph && ctx->stream != nullptr) {
         if (!ctx->gexec_p2p || ctx->g_iters_p2p != iterations) {
             if (ctx->gexec_p2p) { (void)hipGraphExecDestroy(ctx->gexec_p2p); ctx->gexec_p2p = nullptr; }
             hipGraph_t graph = nullptr;
@@ -1129,11 +1260,13 @@ int svicp_run_point2point(svicp_ctx *ctx, int iterations, double T_out[16], svic
     return SVICP_OK;
 }
 
-int svicp_get_history_rt(svicp_ctx *ctx, double *RT_out, double *info_out)
+int svicp_get_history_rt(svicp_ctx *ctx, int capacity_rows, double *RT_out, double *info_out)
 {
     if (!ctx) return SVICP_ERR_ARG;
     if (ctx->last_iters <= 0 || !ctx->last_was_p2p)
         return fail(ctx, SVICP_ERR_ARG, "svicp_get_history_rt: no point-to-point run yet");
+    if (capacity_rows < ctx->last_iters)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_get_history_rt: capacity_rows is below the last run's iterations");
     HIPCHK(hipSetDevice(ctx->device));
     if (RT_out)
         HIPCHK(hipMemcpyAsync(RT_out, ctx->rthist.p, sizeof(double) * 12 * ctx->last_iters,
@@ -1247,7 +1380,7 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
     const bool coherent = ctx->opt.coherent != 0;
     const int total = (int)map.size();
     if (pb != b->pairs.p || mb != b->block_map.p || rb != b->rt_all.p || total != b->total_blocks ||
-        b->g_iters != iterations) {
+        b->g_iters != iterations || b->g_coherent != coherent) {
         if (b->gexec) { (void)hipGraphExecDestroy(b->gexec); b->gexec = nullptr; }
         b->g_iters = -1;
     }
@@ -1284,7 +1417,7 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
     HIPCHK(e0.create());
     HIPCHK(e1.create());
     HIPCHK(hipEventRecord(e0.ev, ctx->stream));
-    if (ctx->opt.use_graph) {
+    if (ctx->opt.use_graph && ctx->stream != nullptr) {
         if (!b->gexec) {
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
@@ -1296,6 +1429,7 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
             (void)hipGraphDestroy(graph);
             if (e != hipSuccess) { b->gexec = nullptr; return fail(ctx, SVICP_ERR_HIP, "hipGraphInstantiate", e); }
             b->g_iters = iterations;
+            b->g_coherent = coherent;
         }
         HIPCHK(hipGraphLaunch(b->gexec, ctx->stream));
     } else {

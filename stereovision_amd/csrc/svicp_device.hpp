@@ -1281,9 +1281,13 @@ __global__ void batch_collect_kernel(const BatchPair *__restrict__ pairs, int co
 
 // One wave: solve the system of iteration `iter` and record the result (the
 // last iteration of a run has no following iteration kernel to do it).
+// dev_out (device memory, or null): the accumulated transform (16 doubles, row-major) and
+// {status, inliers, sum w b^2, |X|} of the last iteration, kRunOutDoubles doubles in all.
+constexpr int kRunOutDoubles = 20;
 __global__ __launch_bounds__(64) void solve_kernel(double *totals, double *deltas,
                                                    IcpState *st, double *X_hist,
-                                                   double *info_hist, int iter, IcpState *host_copy)
+                                                   double *info_hist, int iter, IcpState *host_copy,
+                                                   double *dev_out)
 {
     __shared__ double rt[12];
     solve_and_update(request_sums(totals + (size_t)iter * kNumSums,
@@ -1294,12 +1298,21 @@ __global__ __launch_bounds__(64) void solve_kernel(double *totals, double *delta
     // leave the first delta row clean for the next run, and hand the state to the
     // host through mapped memory (one store per lane instead of a copy command)
     for (int k = threadIdx.x; k < kDeltaRow; k += 64) deltas[k] = 0.0;
+    if (host_copy || dev_out) __threadfence();
     if (host_copy) {
         constexpr int W = sizeof(IcpState) / sizeof(double);
-        __threadfence();
         for (int k = threadIdx.x; k < W; k += 64)
             reinterpret_cast<double *>(host_copy)[k] = reinterpret_cast<volatile double *>(st)[k];
         __threadfence_system();
+    }
+    if (dev_out) {
+        const volatile IcpState *v = st;
+        const int t = threadIdx.x;
+        if (t < 16) dev_out[t] = v->Trans[t];
+        else if (t == 16) dev_out[16] = (double)v->status;
+        else if (t == 17) dev_out[17] = v->S[27];
+        else if (t == 18) dev_out[18] = v->S[28];
+        else if (t == 19) dev_out[19] = v->S[30];
     }
 }
 

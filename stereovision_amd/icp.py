@@ -118,39 +118,49 @@ class Context:
         """Returns (4x4 transform, Info)."""
         T = np.empty(16, np.float64)
         info = Info()
-        self._iters = int(iterations)
         self._check(self._lib.svicp_run(self._h, int(iterations), _dp(T), C.byref(info)))
         return T.reshape(4, 4), info
+
+    def last_iterations(self):
+        """Rows the history calls return: iterations of the last successful run."""
+        k = C.c_int()
+        self._check(self._lib.svicp_last_iterations(self._h, C.byref(k)))
+        return k.value
+
+    def run_enqueue(self, iterations, dev_out20):
+        """svicp_run_enqueue: queues the loop on the context's stream and returns at once.
+        dev_out20: address of 20 doubles of device memory (transform, status, statistics)."""
+        self._check(self._lib.svicp_run_enqueue(self._h, int(iterations), C.c_void_p(int(dev_out20))))
 
     def run_point2point(self, iterations):
         """CPoint2PointICP::run on this context.  Returns (4x4 transform, Info)."""
         T = np.empty(16, np.float64)
         info = Info()
-        self._iters = int(iterations)
         self._check(self._lib.svicp_run_point2point(self._h, int(iterations), _dp(T), C.byref(info)))
         return T.reshape(4, 4), info
 
     def history_rt(self):
         """Per-iteration {R, T} (iters x 12) and {count, sum w d2, step, sum w} (iters x 4)
         of the last point-to-point run."""
-        iters = getattr(self, "_iters", 0)
+        iters = self.last_iterations()
         RT = np.empty((iters, 12), np.float64)
         I = np.empty((iters, 4), np.float64)
-        self._check(self._lib.svicp_get_history_rt(self._h, _dp(RT), _dp(I)))
+        self._check(self._lib.svicp_get_history_rt(self._h, iters, _dp(RT), _dp(I)))
         return RT, I
 
     def history(self):
         """Per-iteration X (iters x 6) and {inliers, sum w b^2, |X|, sum w} (iters x 4)."""
-        iters = getattr(self, "_iters", 0)
+        iters = self.last_iterations()
         X = np.empty((iters, 6), np.float64)
         I = np.empty((iters, 4), np.float64)
-        self._check(self._lib.svicp_get_history(self._h, _dp(X), _dp(I)))
+        self._check(self._lib.svicp_get_history(self._h, iters, _dp(X), _dp(I)))
         return X, I
 
     def search_counts(self):
         """Points searched per iteration of the last run()."""
-        out = np.zeros(getattr(self, "_iters", 0), np.float64)
-        self._check(self._lib.svicp_search_counts(self._h, _dp(out)))
+        iters = self.last_iterations()
+        out = np.zeros(iters, np.float64)
+        self._check(self._lib.svicp_search_counts(self._h, iters, _dp(out)))
         return out
 
     def correspondences(self):
@@ -175,6 +185,9 @@ class Context:
 
     def use_own_stream(self):
         self._check(self._lib.svicp_use_own_stream(self._h))
+
+    def sync(self):
+        self._check(self._lib.svicp_synchronize(self._h))
 
     def shard_begin(self):
         self._check(self._lib.svicp_shard_begin(self._h))
@@ -231,8 +244,6 @@ class Batch:
         T = np.empty((n, 16), np.float64)
         infos = (Info * n)()
         rc = self._lib.svicp_batch_run(self._h, int(iterations), _dp(T), infos)
-        for c in self.contexts:
-            c._iters = int(iterations)
         if rc != 0:
             raise SvicpError(rc, self._lib.svicp_batch_last_error(self._h).decode())
         return T.reshape(n, 4, 4), list(infos)

@@ -562,3 +562,43 @@ def test_options_other_than_the_reference_constants(po, pair, thr, k):
     assert np.array_equal(I[:, 0], want["info"][:, 0])
     assert np.abs(X - want["X"]).max() < 1e-7
     _check_transform(T, want["trans"], _extent(ref))
+
+
+def test_history_rows_come_from_the_library(ctx, synth32):
+    import stereovision_amd as sv
+    ctx.set_target(synth32["target"], synth32["normals"])
+    ctx.set_source(synth32["source"])
+    ctx.run(5)
+    with pytest.raises(sv.SvicpError):
+        ctx.run(0)                                   # refused: the last successful run stays 5
+    assert ctx.last_iterations() == 5
+    X, I = ctx.history()
+    assert X.shape == (5, 6) and I.shape == (5, 4) and np.isfinite(X).all()
+    assert ctx.search_counts().shape == (5,)
+    # arrays smaller than the run are refused instead of overrun
+    import ctypes as C
+    small = np.zeros((3, 6))
+    rc = ctx._lib.svicp_get_history(ctx._h, 3, small.ctypes.data_as(C.POINTER(C.c_double)), None)
+    assert rc == sv._lib.ERR_ARG and not small.any()
+    rc = ctx._lib.svicp_search_counts(ctx._h, 4, small.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == sv._lib.ERR_ARG and not small.any()
+    ctx.run_point2point(4)
+    RT, I = ctx.history_rt()
+    assert RT.shape == (4, 12)
+
+
+def test_default_stream_runs_without_capture(ctx, synth32):
+    """The legacy default stream cannot be captured into a graph: a context told to launch
+    on it runs the loop eagerly and returns the same transform."""
+    ctx.set_target(synth32["target"], synth32["normals"])
+    ctx.set_source(synth32["source"])
+    T_own, _ = ctx.run(6)
+    ctx.set_stream(0)
+    T_null, info = ctx.run(6)
+    Tp_null, _ = ctx.run_point2point(3)
+    ctx.use_own_stream()
+    T_again, _ = ctx.run(6)
+    Tp_own, _ = ctx.run_point2point(3)
+    assert info.status == 0
+    assert np.abs(T_null - T_own).max() < 1e-10 and np.abs(T_again - T_own).max() < 1e-10
+    assert np.abs(Tp_null - Tp_own).max() < 1e-9

@@ -40,6 +40,10 @@ def test_two_shards_in_one_process_match_unsharded(po):
         for eng in engines:
             eng.update(total)
     outs = [eng.finish() for eng in engines]
+    # the history's row count comes from the library, also after sharded stepping
+    Xs, Is = engines[0].ctx.history()
+    assert Xs.shape == (5, 6) and Is.shape == (5, 4)
+    assert np.abs(Xs - full.history()[0]).max() < 1e-10
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.abs(outs[0][0] - T_full).max() < 1e-10
     assert outs[0][1].inliers == info_full.inliers

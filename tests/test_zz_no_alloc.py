@@ -1,0 +1,77 @@
+"""svicp_run_enqueue (the entry point that allocates nothing) against svicp_run, through the
+C ABI: two calls in a row on one context, the second with a smaller source, each compared with
+svicp_run on the same inputs and with the CPU oracle.  The workspace is a file-scope device
+array that keeps the first call's contents, so the second call also proves that what must
+start at zero is cleared.  Tolerance: the transform within 1e-9 (both paths add their fp64 tile
+sums by atomics in arrival order, which moves the last bits), status and inlier count exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _enqueue(ctx, iters):
+    import torch
+    out = torch.full((20,), float("nan"), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    ctx.run_enqueue(iters, out.data_ptr())
+    ctx.sync()
+    assert torch.cuda.memory_allocated() == before
+    return out.cpu().numpy()
+
+
+def test_enqueue_matches_run_twice_in_a_row(po):
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+
+    tgt, nrm, src, _ = synth.make_pair(96, pair=3)
+    small = np.ascontiguousarray(src[: 40 * 96 + 17])          # ragged last tile, fewer tiles
+    tree = po.KDTree(tgt)
+    with sv.Context(0) as ref, sv.Context(0) as ctx:
+        ref.set_target(tgt, nrm)
+        ctx.set_target(tgt, nrm)
+        for cloud, iters in ((src, 12), (small, 7)):
+            ref.set_source(cloud)
+            T_ref, info_ref = ref.run(iters)
+            moved_ref = ref.get_source()
+            ctx.set_source(cloud)
+            out = _enqueue(ctx, iters)
+            T = out[:16].reshape(4, 4)
+            assert np.abs(T - T_ref).max() < 1e-9
+            assert out[16] == 0 and out[17] == info_ref.inliers
+            assert abs(out[18] - info_ref.weighted_sq_residual) <= 1e-9 * abs(info_ref.weighted_sq_residual)
+            assert abs(out[19] - info_ref.step_norm) < 1e-9
+            assert np.array_equal(ctx.get_source(), moved_ref)
+            expect = po.icp_point2plane(tree, nrm, cloud, iters)
+            assert np.abs(T - expect["trans"]).max() < 1e-8
+            with pytest.raises(sv.SvicpError):
+                ctx.history()                                     # the history stays in the workspace
+
+
+def test_enqueue_rejects_what_exceeds_the_workspace(synth32):
+    import stereovision_amd as sv
+    with sv.Context(0) as ctx:
+        ctx.set_target(synth32["target"], synth32["normals"])
+        ctx.set_source(synth32["source"])
+        import torch
+        out = torch.zeros(20, dtype=torch.float64, device="cuda:0")
+        for bad in (0, 129):
+            with pytest.raises(sv.SvicpError) as e:
+                ctx.run_enqueue(bad, out.data_ptr())
+            assert e.value.status == sv._lib.ERR_ARG
+        with pytest.raises(sv.SvicpError):
+            ctx.run_enqueue(5, 0)
+        # more points than the workspace's 4096 tiles hold
+        big = np.zeros((2050 * 2050, 3), np.float32)
+        big[:, 0] = np.arange(len(big), dtype=np.float32) * 1e-3
+        ctx.set_source(big)
+        with pytest.raises(sv.SvicpError) as e:
+            ctx.run_enqueue(5, out.data_ptr())
+        assert e.value.status == sv._lib.ERR_ARG and "4194304" in str(e.value)
+        ctx.set_source(synth32["source"])
+        # svicp_run still works on the context afterwards
+        ctx.run_enqueue(5, out.data_ptr())
+        ctx.sync()
+        T, _ = ctx.run(5)
+        assert np.abs(out[:16].cpu().numpy().reshape(4, 4) - T).max() < 1e-9
