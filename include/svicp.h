@@ -270,6 +270,18 @@ int svicp_iteration_times(svicp_ctx *ctx, double *fused_ms_out, double *solve_ms
  * loop uses it; exact = 1: unbounded exact search. */
 int svicp_time_nn(svicp_ctx *ctx, int exact, int reps, double *avg_ms);
 
+/* Measurement only: runs, `reps` times over the resident source, a kernel that issues
+ * the vector-memory instructions of the capped 1-NN search and nothing else, and
+ * reports its average duration and the wave-level vector-memory instructions per run.
+ * real_addresses = 1: per query the directory and probe-record look-ups and exactly the
+ * candidate loads the search makes (four at a time as the search does, no distance
+ * arithmetic, no result written);
+ * real_addresses = 0: per_query 16-byte loads per query from hashed places of the
+ * sorted target.  The first is the floor of a per-lane gather search on this GPU for
+ * this pair; the second the rate of the gather path without any locality. */
+int svicp_time_gather(svicp_ctx *ctx, int real_addresses, int per_query, int reps,
+                      double *avg_ms, double *wave_instructions);
+
 /* Sizes of the resident clouds. */
 int svicp_sizes(const svicp_ctx *ctx, int64_t *m, int64_t *n);
 

@@ -72,6 +72,7 @@ SYMBOLS = {
     "svicp_kernel_times": (C.c_int, [_ctx, _dp, _dp, C.POINTER(C.c_int)]),
     "svicp_iteration_times": (C.c_int, [_ctx, _dp, _dp]),
     "svicp_time_nn": (C.c_int, [_ctx, C.c_int, C.c_int, _dp]),
+    "svicp_time_gather": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "svicp_sizes": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "svicp_search_counts": (C.c_int, [_ctx, C.c_int, _dp]),
     "svicp_run_point2point": (C.c_int, [_ctx, C.c_int, _dp, C.POINTER(Info)]),

@@ -1179,6 +1179,51 @@ int svicp_time_nn(svicp_ctx *ctx, int exact, int reps, double *avg_ms)
     return SVICP_OK;
 }
 
+int svicp_time_gather(svicp_ctx *ctx, int real_addresses, int per_query, int reps, double *avg_ms,
+                      double *wave_instructions)
+{
+    if (!ctx || !avg_ms || reps < 1 || per_query < 0 || per_query > 4096)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_time_gather: bad argument");
+    if (!ctx->have_target || !ctx->have_source || ctx->n == 0 || ctx->m == 0)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_time_gather: set a non-empty target and source first");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(ctx->n_unres.reserve(sizeof(unsigned long long) * 2));
+    const int64_t n = ctx->n;
+    const float *x = ctx->cur ? ctx->wx.as<float>() : ctx->sx0.as<float>();
+    const float *y = ctx->cur ? ctx->wy.as<float>() : ctx->sy0.as<float>();
+    const float *z = ctx->cur ? ctx->wz.as<float>() : ctx->sz0.as<float>();
+    const int grid = std::min(cdiv(n, kBlockThreads), ctx->num_cus * 8);
+    unsigned long long *cnt = ctx->n_unres.as<unsigned long long>();
+    auto launch = [&](unsigned long long *count) {
+        if (real_addresses)
+            hipLaunchKernelGGL((gather_probe_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
+                               ctx->g, x, y, z, (int)n, per_query, reinterpret_cast<unsigned *>(cnt + 1), count);
+        else
+            hipLaunchKernelGGL((gather_probe_kernel<false>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
+                               ctx->g, x, y, z, (int)n, per_query, reinterpret_cast<unsigned *>(cnt + 1), count);
+    };
+    ScopedEvent a, b;
+    HIPCHK(a.create());
+    HIPCHK(b.create());
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * 2, ctx->stream));
+    launch(cnt);                                // warm-up; the only launch that counts
+    LAUNCHCHK("gather_probe_kernel");
+    HIPCHK(hipEventRecord(a.ev, ctx->stream));
+    for (int r = 0; r < reps; ++r) launch(nullptr);
+    LAUNCHCHK("gather_probe_kernel");
+    HIPCHK(hipEventRecord(b.ev, ctx->stream));
+    int rc = ensure_small(ctx);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->h_small, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a.ev, b.ev));
+    *avg_ms = (double)ms / reps;
+    if (wave_instructions)
+        *wave_instructions = (double)*reinterpret_cast<unsigned long long *>(ctx->h_small);
+    return SVICP_OK;
+}
+
 /* ---- point-to-point variant --------------------------------------------- */
 
 int svicp_run_point2point(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info)

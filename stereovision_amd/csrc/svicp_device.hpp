@@ -1424,6 +1424,91 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
     }
 }
 
+// ------------------------------------------------------------------------
+// Gather probe (measurement only): the vector-memory instruction stream of the capped
+// search with nothing else around it, to see what the texture-address path of this GPU
+// delivers for it.  REAL: every query makes the same table look-ups (directory, the two
+// words of its probe record) and loads exactly the candidates nn_capped would, four at a
+// time as the search does, no distance arithmetic, no running best, nothing written per query.  !REAL:
+// `per_query` 16-byte loads per lane from hashed places of the sorted target (no look-ups,
+// no locality between lanes), eight in flight.  With `instr` non-null every wave adds the
+// vector-memory instructions it issued to *instr.
+// ------------------------------------------------------------------------
+template <bool REAL>
+__global__ __launch_bounds__(kBlockThreads) void gather_probe_kernel(
+    GridDesc g, const float *__restrict__ qx_, const float *__restrict__ qy_,
+    const float *__restrict__ qz_, int n, int per_query, unsigned *__restrict__ sink,
+    unsigned long long *__restrict__ instr)
+{
+    const long long chunks = ((long long)n + kBlockThreads - 1) / kBlockThreads;
+    const long long per_block = (chunks + gridDim.x - 1) / gridDim.x;
+    const long long first = (long long)xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * per_block;
+    const long long last = first + per_block < chunks ? first + per_block : chunks;
+    unsigned acc = 0;
+    unsigned long long issued = 0;      // wave-level count (uniform)
+    for (long long c = first; c < last; ++c) {
+        const long long i = c * kBlockThreads + threadIdx.x;
+        const bool live = i < n;
+        const long long ic = live ? i : 0;
+        const float qx = qx_[ic], qy = qy_[ic], qz = qz_[ic];
+        issued += 3;
+        unsigned T = 0, P1 = 0, P2 = 0, P3 = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+        if (REAL) {
+            int cx, cy, cz;
+            uint2 run[4] = { make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u) };
+            if (live && probe_origin(g, qx, qy, qz, cx, cy, cz)) {
+                const int rank = g.dir[dir_index(g, cx, cy, cz)];
+                const size_t e = rank >= 0 ? (size_t)rank * 64 + cell_local(cx, cy, cz) : 0;
+                const uint4 a = g.quad[2 * e], b = g.quad[2 * e + 1];
+                if (rank >= 0) {
+                    run[0] = make_uint2(a.x, a.y); run[1] = make_uint2(a.z, a.w);
+                    run[2] = make_uint2(b.x, b.y); run[3] = make_uint2(b.z, b.w);
+                }
+            }
+            issued += 3;
+            P1 = run[0].y - run[0].x;
+            P2 = P1 + (run[1].y - run[1].x);
+            P3 = P2 + (run[2].y - run[2].x);
+            T = P3 + (run[3].y - run[3].x);
+            o0 = run[0].x; o1 = run[1].x - P1; o2 = run[2].x - P2; o3 = run[3].x - P3;
+        } else {
+            T = live ? (unsigned)per_query : 0u;
+        }
+        // groups of G loads (the search: 4); a lane whose list has ended drops out, as in the search
+        constexpr int G = REAL ? 4 : 8;
+        if (instr) {      // the counting launch only: the wave walks as many groups as its longest lane
+            unsigned Tmax = T;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) Tmax = max(Tmax, (unsigned)__shfl_xor((int)Tmax, off, 64));
+            issued += (unsigned long long)((Tmax + G - 1) / G) * G;
+        }
+        for (unsigned f = 0; f < T; f += G) {
+            float4 p[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const unsigned ff = f + k;
+                unsigned j;
+                if (REAL) {
+                    j = ff + (ff < P1 ? o0 : ff < P2 ? o1 : ff < P3 ? o2 : o3);
+                    j = ff < T ? j : 0u;
+                } else {
+                    unsigned hsh = ((unsigned)i * 2654435761u) ^ (ff * 0x9E3779B9u);
+                    hsh ^= hsh >> 15; hsh *= 0x85EBCA6Bu; hsh ^= hsh >> 13;
+                    j = ff < T ? hsh % (unsigned)g.m : 0u;
+                }
+                p[k] = g.pts[j];
+            }
+#pragma unroll
+            // all four words are used, so that the loads stay 16-byte loads
+            for (int k = 0; k < G; ++k)
+                acc ^= (__float_as_uint(p[k].w) + __float_as_uint(p[k].x)) ^ (__float_as_uint(p[k].y) + __float_as_uint(p[k].z));
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;      // keeps the loads alive
+    // (same-address atomics serialise at about 6 ns each: counted in a launch of its own)
+    if (instr && (threadIdx.x & 63) == 0) atomicAdd(instr, issued);
+}
+
 // One block per queued query: scan the whole target.
 __global__ __launch_bounds__(kBlockThreads) void nn1_brute_kernel(
     GridDesc g, const float *__restrict__ qx_, const float *__restrict__ qy_,

@@ -224,6 +224,14 @@ class Context:
         return ms.value
 
 
+    def time_gather(self, real_addresses=True, per_query=16, reps=10):
+        """(average ms, wave-level vector-memory instructions per run) of the gather probe."""
+        ms, ins = C.c_double(), C.c_double()
+        self._check(self._lib.svicp_time_gather(self._h, 1 if real_addresses else 0, int(per_query),
+                                                int(reps), C.byref(ms), C.byref(ins)))
+        return ms.value, ins.value
+
+
 class Batch:
     """Many independent pairs advanced together, one kernel launch per iteration
     (svicp_batch_* of include/svicp.h).  `contexts` already hold target and source."""
