@@ -32,7 +32,8 @@ enum {
     SVICP_ERR_HIP = 2,       /* a HIP runtime call failed (see svicp_last_error)   */
     SVICP_ERR_GRID = 3,      /* target extent / cell edge too large for the grid   */
     SVICP_ERR_SINGULAR = 4,  /* the 6x6 normal matrix was not positive definite    */
-    SVICP_ERR_NO_DEVICE = 5  /* no gfx950 device / library built without a device  */
+    SVICP_ERR_NO_DEVICE = 5, /* no gfx950 device / library built without a device  */
+    SVICP_ERR_COMM = 6       /* RCCL missing or a collective call failed            */
 };
 
 /* Tunables.  Defaults are the reference's hard-coded constants. */
@@ -182,6 +183,30 @@ int svicp_use_own_stream(svicp_ctx *ctx);
 /* Waits until everything queued on the context's stream has completed (what a
  * caller of svicp_run_enqueue does before it reads dev_out20 from the host). */
 int svicp_synchronize(svicp_ctx *ctx);
+
+/* The whole sharded registration in one call, the collective included.  Every rank
+ * (one process and one context per GPU) holds the whole target and its part of the
+ * source and calls svicp_shard_run with the same iteration count.  Per iteration: one
+ * launch of the iteration kernel, then one RCCL all-reduce (sum, 128 doubles: the
+ * rank's change of the 32 sums in the four copies the kernel keeps) on the context's
+ * stream, in place; the next launch solves from the summed numbers on every rank
+ * alike, so nothing is broadcast.  With options.use_graph the loop is captured in one
+ * HIP graph (collectives included) and replayed; a runtime that refuses to capture the
+ * collective gets the same launches one by one.  No host round trip per iteration
+ * either way.  The reference is single-process (test.cpp:14-29): nothing to cite.
+ *
+ * svicp_comm_unique_id: rank 0 calls it and sends the 128 bytes to the other ranks by
+ * any means (MPI, torch.distributed, a file).  svicp_comm_init: every rank, with the
+ * same bytes; collective (returns when all ranks have called).  RCCL is looked up at run
+ * time: the copy already loaded in the process (PyTorch's) or librccl.so.1.
+ * A context without a communicator runs svicp_shard_run alone (world size 1). */
+int svicp_comm_unique_id(unsigned char id_out[128]);
+int svicp_comm_init(svicp_ctx *ctx, const unsigned char id[128], int rank, int world_size);
+int svicp_comm_destroy(svicp_ctx *ctx);
+int svicp_shard_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info);
+/* captured: 1 when the last svicp_shard_run replayed a captured graph; world_size of
+ * the communicator (1 without one).  Either pointer may be NULL. */
+int svicp_shard_run_mode(const svicp_ctx *ctx, int *captured, int *world_size);
 
 /* Resets the accumulated transform and the iteration counter. */
 int svicp_shard_begin(svicp_ctx *ctx);

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVICP_LIBRARY") or os.path.join(_HERE, "libsvicp.so")   # the override serves A/B builds
 
-OK, ERR_ARG, ERR_HIP, ERR_GRID, ERR_SINGULAR, ERR_NO_DEVICE = range(6)
+OK, ERR_ARG, ERR_HIP, ERR_GRID, ERR_SINGULAR, ERR_NO_DEVICE, ERR_COMM = range(7)
 
 
 class SvicpError(RuntimeError):
@@ -65,6 +65,11 @@ SYMBOLS = {
     "svicp_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "svicp_use_own_stream": (C.c_int, [_ctx]),
     "svicp_synchronize": (C.c_int, [_ctx]),
+    "svicp_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "svicp_comm_init": (C.c_int, [_ctx, C.c_char_p, C.c_int, C.c_int]),
+    "svicp_comm_destroy": (C.c_int, [_ctx]),
+    "svicp_shard_run": (C.c_int, [_ctx, C.c_int, _dp, C.POINTER(Info)]),
+    "svicp_shard_run_mode": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "svicp_shard_begin": (C.c_int, [_ctx]),
     "svicp_shard_accumulate": (C.c_int, [_ctx, C.c_void_p]),
     "svicp_shard_update": (C.c_int, [_ctx, C.c_void_p]),

@@ -10,7 +10,10 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and enumerators only: the library is bound at run time (rccl_api)
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -135,6 +138,12 @@ struct svicp_ctx {
     int timed_launches = 0;
 
     int shard_iter = 0;
+    // sharded runs inside the library: the communicator over the ranks of one registration
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    hipGraphExec_t gexec_shard = nullptr;
+    int g_iters_shard = -1;
+    bool shard_capture_failed = false;   // this runtime would not capture the collective: eager from then on
     unsigned char *enq_scratch = nullptr;   // this device's copy of `scratch`
 
     // point-to-point variant
@@ -193,6 +202,8 @@ void drop_graph(svicp_ctx *ctx)
     ctx->g_iters = -1;
     if (ctx->gexec_p2p) { (void)hipGraphExecDestroy(ctx->gexec_p2p); ctx->gexec_p2p = nullptr; }
     ctx->g_iters_p2p = -1;
+    if (ctx->gexec_shard) { (void)hipGraphExecDestroy(ctx->gexec_shard); ctx->gexec_shard = nullptr; }
+    ctx->g_iters_shard = -1;
 }
 
 // A pinned page for results of a few bytes: a copy into pageable memory costs tens of
@@ -449,6 +460,74 @@ void fill_info(const svicp_ctx *ctx, int iters, svicp_info *info)
     info->step_norm = s->S[30];
 }
 
+// RCCL, bound at run time: a process that already holds an RCCL (PyTorch brings its own) must
+// use that one, and a caller that never shards needs none.
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *loaded[] = { "librccl.so.1", "librccl.so" };
+        for (const char *name : loaded)
+            if (!api.handle) api.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        const char *fresh[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        for (const char *name : fresh)
+            if (!api.handle) api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!api.handle) { api.error = "librccl.so could not be loaded"; return; }
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+        if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy || !api.GetErrorString) {
+            api.error = "librccl.so lacks an entry point this library needs";
+            api.handle = nullptr;
+        }
+    });
+    return &api;
+}
+
+int fail_rccl(svicp_ctx *ctx, const char *what, ncclResult_t r)
+{
+    RcclApi *api = rccl_api();
+    std::string msg = std::string(what) + ": " + (api->GetErrorString ? api->GetErrorString(r) : "RCCL error");
+    return fail(ctx, SVICP_ERR_COMM, msg.c_str());
+}
+
+// The sharded loop on ctx->stream: iteration k's kernel leaves this rank's change of the sums
+// in delta row k (kDeltaCopies copies of 32 doubles); one all-reduce sums that row over the
+// ranks where it lies; iteration k + 1's kernel (or the closing solve) adds the copies to the
+// totals and solves, on every rank from the same numbers.
+int enqueue_shard_loop(svicp_ctx *ctx, int iters)
+{
+    RcclApi *api = rccl_api();
+    const LoopBufs b = own_bufs(ctx);
+    for (int k = 0; k < iters; ++k) {
+        launch_iteration(ctx, k, b);
+        LAUNCHCHK("icp_iterate_kernel");
+        if (ctx->comm) {
+            double *row = b.deltas + (size_t)k * kDeltaRow;
+            ncclResult_t r = api->AllReduce(row, row, kDeltaRow, ncclDouble, ncclSum, ctx->comm, ctx->stream);
+            if (r != ncclSuccess) return fail_rccl(ctx, "ncclAllReduce", r);
+        }
+    }
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, b.totals, b.deltas, b.state,
+                       b.xhist, b.ihist, iters - 1, ctx->h_state_dev, (double *)nullptr);
+    LAUNCHCHK("solve_kernel");
+    return SVICP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -514,6 +593,7 @@ int svicp_destroy(svicp_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     drop_graph(ctx);
+    if (ctx->comm) { (void)rccl_api()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     DevBuf *bufs[] = { &ctx->tgt_aos, &ctx->nrm_aos, &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->run2, &ctx->quad,
                        &ctx->end1, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx, &ctx->wy, &ctx->wz,
@@ -1049,6 +1129,115 @@ int svicp_knn(svicp_ctx *ctx, const float *query_aos, int64_t n, int k, int32_t 
     HIPCHK(hipMemcpyAsync(d2_out, ctx->knn_d2.p, sizeof(float) * n * k, hipMemcpyDeviceToHost,
                           ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SVICP_OK;
+}
+
+int svicp_comm_unique_id(unsigned char id_out[128])
+{
+    if (!id_out) return fail(nullptr, SVICP_ERR_ARG, "svicp_comm_unique_id: NULL argument");
+    RcclApi *api = rccl_api();
+    if (!api->handle) return fail(nullptr, SVICP_ERR_COMM, api->error.c_str());
+    static_assert(sizeof(ncclUniqueId) == 128, "the identifier travels as 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail_rccl(nullptr, "ncclGetUniqueId", r);
+    std::memcpy(id_out, &id, sizeof id);
+    return SVICP_OK;
+}
+
+int svicp_comm_init(svicp_ctx *ctx, const unsigned char id[128], int rank, int world_size)
+{
+    if (!ctx || !id) return fail(ctx, SVICP_ERR_ARG, "svicp_comm_init: NULL argument");
+    if (world_size < 1 || rank < 0 || rank >= world_size)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_comm_init: rank must be in [0, world_size)");
+    if (ctx->comm) return fail(ctx, SVICP_ERR_ARG, "svicp_comm_init: the context already has a communicator");
+    RcclApi *api = rccl_api();
+    if (!api->handle) return fail(ctx, SVICP_ERR_COMM, api->error.c_str());
+    HIPCHK(hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = api->CommInitRank(&comm, world_size, uid, rank);
+    if (r != ncclSuccess) return fail_rccl(ctx, "ncclCommInitRank", r);
+    ctx->comm = comm;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world_size;
+    drop_graph(ctx);
+    return SVICP_OK;
+}
+
+int svicp_comm_destroy(svicp_ctx *ctx)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (!ctx->comm) return SVICP_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    drop_graph(ctx);
+    ncclResult_t r = rccl_api()->CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_rank = 0;
+    ctx->comm_world = 1;
+    if (r != ncclSuccess) return fail_rccl(ctx, "ncclCommDestroy", r);
+    return SVICP_OK;
+}
+
+int svicp_shard_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (iterations < 1 || !T_out)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_shard_run: iterations must be >= 1 and T_out non-NULL");
+    if (!ctx->have_target || !ctx->have_source)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_shard_run: set the target and this rank's part of the source first");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_iteration_buffers(ctx, iterations);
+    if (rc) return rc;
+    const bool capture = ctx->opt.use_graph && ctx->stream != nullptr && !ctx->shard_capture_failed;
+    bool launched = false;
+    if (capture) {
+        if (!ctx->gexec_shard || ctx->g_iters_shard != iterations) {
+            if (ctx->gexec_shard) { (void)hipGraphExecDestroy(ctx->gexec_shard); ctx->gexec_shard = nullptr; }
+            ctx->g_iters_shard = -1;
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_shard_loop(ctx, iterations);
+            hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+            if (rc == SVICP_OK && e == hipSuccess && graph)
+                e = hipGraphInstantiate(&ctx->gexec_shard, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc != SVICP_OK || e != hipSuccess || !ctx->gexec_shard) {
+                // a runtime that cannot capture the collective: launch one by one from now on
+                (void)hipGetLastError();
+                ctx->gexec_shard = nullptr;
+                ctx->shard_capture_failed = true;
+            } else {
+                ctx->g_iters_shard = iterations;
+            }
+        }
+        if (ctx->gexec_shard) {
+            HIPCHK(hipGraphLaunch(ctx->gexec_shard, ctx->stream));
+            launched = true;
+        }
+    }
+    if (!launched) {
+        rc = enqueue_shard_loop(ctx, iterations);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // the last kernel wrote h_state
+    ctx->cur = iterations > 1 ? 1 : 0;
+    ctx->last_iters = iterations;
+    ctx->last_was_p2p = false;
+    std::memcpy(T_out, ctx->h_state->Trans, sizeof(double) * 16);
+    fill_info(ctx, iterations, info);
+    if (ctx->h_state->status == SVICP_ERR_SINGULAR)
+        return fail(ctx, SVICP_ERR_SINGULAR, "svicp_shard_run: normal matrix not positive definite");
+    return SVICP_OK;
+}
+
+int svicp_shard_run_mode(const svicp_ctx *ctx, int *captured, int *world_size)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (captured) *captured = ctx->gexec_shard != nullptr ? 1 : 0;
+    if (world_size) *world_size = ctx->comm ? ctx->comm_world : 1;
     return SVICP_OK;
 }
 

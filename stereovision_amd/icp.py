@@ -189,6 +189,35 @@ class Context:
     def sync(self):
         self._check(self._lib.svicp_synchronize(self._h))
 
+    # -- sharded registration inside the library (RCCL) --
+    def comm_unique_id(self):
+        """128 bytes that identify a new communicator (rank 0 makes them, every rank gets them)."""
+        buf = C.create_string_buffer(128)
+        rc = self._lib.svicp_comm_unique_id(buf)
+        if rc != 0:
+            raise SvicpError(rc, self._lib.svicp_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world_size):
+        assert len(unique_id) == 128
+        self._check(self._lib.svicp_comm_init(self._h, C.c_char_p(bytes(unique_id)), int(rank), int(world_size)))
+
+    def comm_destroy(self):
+        self._check(self._lib.svicp_comm_destroy(self._h))
+
+    def shard_run(self, iterations):
+        """svicp_shard_run: returns (4x4 transform, Info), the same on every rank."""
+        T = np.empty(16, np.float64)
+        info = Info()
+        self._check(self._lib.svicp_shard_run(self._h, int(iterations), _dp(T), C.byref(info)))
+        return T.reshape(4, 4), info
+
+    def shard_run_mode(self):
+        """(captured in a graph?, world size) of the last shard_run."""
+        a, b = C.c_int(), C.c_int()
+        self._check(self._lib.svicp_shard_run_mode(self._h, C.byref(a), C.byref(b)))
+        return bool(a.value), b.value
+
     def shard_begin(self):
         self._check(self._lib.svicp_shard_begin(self._h))
 

@@ -72,3 +72,25 @@ def run_sharded(engine, iterations, group=None):
         buf = all_reduce_sums(buf, group)
         engine.update(buf)
     return engine.finish()
+
+
+def init_comm(ctx, group=None):
+    """Gives `ctx` an RCCL communicator over the ranks of `group` (or a 1-rank one without
+    torch.distributed): rank 0 asks the library for the 128-byte identifier, torch.distributed
+    carries it to the other ranks (any backend: it is host bytes), every rank joins."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                   group=group)
+        ctx.comm_init(box[0], rank, world)
+    else:
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+
+
+def run_sharded_native(ctx, iterations):
+    """The same loop as run_sharded, inside the library (svicp_shard_run): iteration kernel
+    and RCCL all-reduce per iteration on one stream, captured in a HIP graph; no Python and
+    no host round trip per iteration.  `ctx` holds the whole target and this rank's part of
+    the source; with more than one rank it needs init_comm first."""
+    return ctx.shard_run(int(iterations))

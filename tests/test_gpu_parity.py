@@ -501,13 +501,14 @@ def test_batch_many_small_pairs_throughput_property():
     print(f"batch of 64 x 16384 points, 30 iterations: {batch.last_ms():.3f} ms")
 
 
-@pytest.mark.parametrize("side,iters", [(1024, 4), (4096, 2)])
-def test_full_size_iterations_against_oracle(ctx, po, side, iters):
-    """The benchmark's 1M-point pair and the 16.8M-point pair of the sharded configuration,
+@pytest.mark.parametrize("side,iters,frac", [(1024, 4, None), (4096, 2, None), (1024, 4, 0.7), (4096, 2, 0.7)])
+def test_full_size_iterations_against_oracle(ctx, po, side, iters, frac):
+    """The benchmark's 1M-point pair and the 16.8M-point pair of the sharded configuration, at
+    the fixed start pose and at the pose that leaves 70 % of the source within the threshold,
     first iterations, against the oracle on all host threads: inlier counts equal, solve
     results within 1e-9 (rotation) / 1e-9 x extent (translation)."""
     from stereovision_amd import synth
-    tgt, nrm, src, _ = synth.make_pair(side)
+    tgt, nrm, src, _ = synth.make_pair(side, inlier_frac=frac)
     ctx.set_target(tgt, nrm)
     ctx.set_source(src)
     T, info = ctx.run(iters)

@@ -130,3 +130,42 @@ def test_calibration_views_split_over_two_contexts(po):
             assert np.array_equal(out[n], whole[n][b:e])
     want = po.stereo_eval_sparse(start, 5, w, l, r, False)
     assert np.abs(outs[0]["LL"] - want["LL"]).max() / np.abs(want["LL"]).max() < 1e-6
+
+
+def test_shard_run_with_one_rank_communicator_equals_run(po):
+    """svicp_shard_run (iteration kernel + RCCL all-reduce per iteration, captured in one HIP
+    graph) with a one-rank communicator against svicp_run on the same pair, and against the
+    oracle; then without a communicator, and eagerly."""
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+    from stereovision_amd.sharded import init_comm, run_sharded_native
+    tgt, nrm, src, _ = synth.make_pair(160, pair=2)
+    with sv.Context(0) as ref, sv.Context(0) as ctx:
+        for c in (ref, ctx):
+            c.set_target(tgt, nrm)
+            c.set_source(src)
+        T_ref, info_ref = ref.run(8)
+        X_ref, _ = ref.history()
+        T0, info0 = run_sharded_native(ctx, 8)              # no communicator: world size 1
+        assert ctx.shard_run_mode() == (True, 1)
+        assert np.abs(T0 - T_ref).max() < 1e-10
+        init_comm(ctx)
+        ctx.set_source(src)
+        T1, info1 = run_sharded_native(ctx, 8)
+        captured, world = ctx.shard_run_mode()
+        assert world == 1
+        print("collective captured in the graph:", captured)
+        assert np.abs(T1 - T_ref).max() < 1e-10
+        assert info1.inliers == info_ref.inliers and info1.iterations == 8
+        X1, _ = ctx.history()
+        assert np.abs(X1 - X_ref).max() < 1e-10
+        assert np.array_equal(ctx.get_source(), ref.get_source())
+        T1b, _ = run_sharded_native(ctx, 8)                 # replay
+        assert np.abs(T1b - T_ref).max() < 1e-10
+        ctx.set_options(use_graph=0)
+        T2, _ = run_sharded_native(ctx, 8)
+        assert ctx.shard_run_mode()[0] is False
+        assert np.abs(T2 - T_ref).max() < 1e-10
+        ctx.comm_destroy()
+        r = po.icp_point2plane(po.KDTree(tgt), nrm, src, 8)
+        assert np.abs(T1 - r["trans"]).max() < 1e-8

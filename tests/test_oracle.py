@@ -226,3 +226,21 @@ def test_point2point_registers_the_bundled_pair(po, pair):
     assert refmath.rot_angle(a["trans"][:3, :3], b["trans"][:3, :3]) < 1e-6
     d = np.abs(a["src"] - ref[a["idx"][-1]]).max()
     assert d < 1e-2
+
+
+@pytest.mark.parametrize("side", [192, 512])
+def test_synthetic_pair_with_inlier_fraction(side):
+    """make_pair(inlier_frac=0.7): at least 70 % of the source starts within the weight
+    function's threshold (CPoint2PlaneICP.cpp:68) of a target point, at any extent; the
+    default pose of the same pair leaves far fewer once the cloud is large."""
+    from scipy.spatial import cKDTree
+    from stereovision_amd import synth
+    tgt, _, src, P = synth.make_pair(side, inlier_frac=0.7)
+    d, _ = cKDTree(tgt).query(src)
+    frac = float((d * d <= 5.0).mean())
+    assert 0.70 <= frac <= 0.85, frac
+    assert np.allclose(P[:3, :3] @ P[:3, :3].T, np.eye(3), atol=1e-12)
+    if side == 512:
+        _, _, src0, _ = synth.make_pair(side)
+        d0, _ = cKDTree(tgt).query(src0)
+        assert (d0 * d0 <= 5.0).mean() < 0.40
