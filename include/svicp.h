@@ -263,6 +263,24 @@ typedef struct svicp_batch svicp_batch;
 int svicp_batch_create(svicp_ctx **ctxs, int count, svicp_batch **out);
 int svicp_batch_destroy(svicp_batch *batch);
 const char *svicp_batch_last_error(const svicp_batch *batch);
+/* The same batch from flat arrays, for hundreds of pairs: pair i's target is points
+ * tgt_offsets[i] .. tgt_offsets[i + 1] - 1 of tgt_xyz (and of tgt_normals, or NULL to
+ * estimate them), its source src_offsets[i] .. src_offsets[i + 1] - 1 of src_xyz (offsets
+ * in points, count + 1 entries each).  One stream and one arena of device memory for all
+ * pairs (a few large allocations instead of about 25 per pair), the set-up scratch shared.
+ * The batch owns its pairs: svicp_batch_pair lends pair i's context for svicp_get_source,
+ * svicp_get_history, svicp_correspondences (not svicp_knn / svicp_get_normals: the cell
+ * tables of the exact search and the caller-order normals are not kept per pair; do not
+ * destroy it or set clouds on it).  opt: NULL for the defaults.  On failure the text is
+ * in svicp_last_error(NULL). */
+int svicp_batch_create_from_arrays(int device_id, int count, const int64_t *tgt_offsets,
+                                   const float *tgt_xyz, const float *tgt_normals,
+                                   const int64_t *src_offsets, const float *src_xyz,
+                                   const svicp_options *opt, svicp_batch **out);
+int svicp_batch_pair(svicp_batch *batch, int index, svicp_ctx **ctx_out);
+/* Pairs, host time of svicp_batch_create_from_arrays (ms; 0 for svicp_batch_create) and
+ * bytes of device memory its arena holds.  Any pointer may be NULL. */
+int svicp_batch_info(const svicp_batch *batch, int *count, double *setup_ms, double *device_bytes);
 /* T_out: count x 16 doubles (row-major 4x4 per pair); info_out: count entries or NULL.
  * Returns SVICP_ERR_SINGULAR if any pair's system was singular (that pair's
  * info.status says which). */

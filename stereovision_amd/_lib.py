@@ -83,6 +83,11 @@ SYMBOLS = {
     "svicp_run_point2point": (C.c_int, [_ctx, C.c_int, _dp, C.POINTER(Info)]),
     "svicp_get_history_rt": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
     "svicp_batch_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.POINTER(C.c_void_p)]),
+    "svicp_batch_create_from_arrays": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64), _fp, _fp,
+                                                 C.POINTER(C.c_int64), _fp, C.POINTER(Options),
+                                                 C.POINTER(C.c_void_p)]),
+    "svicp_batch_pair": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(_ctx)]),
+    "svicp_batch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), _dp, _dp]),
     "svicp_batch_destroy": (C.c_int, [C.c_void_p]),
     "svicp_batch_last_error": (C.c_char_p, [C.c_void_p]),
     "svicp_batch_run": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(Info)]),

@@ -2,6 +2,7 @@
 // Owns device memory, builds the search grid, launches the kernels of
 // svicp_device.hpp and replays the iteration loop as one HIP graph.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -27,20 +28,72 @@ namespace {
 
 thread_local std::string g_create_error = "";
 
+// Device memory handed out in slices from a few large allocations (a batch of hundreds of
+// pairs would otherwise make thousands of hipMalloc calls).  Slices are never returned one
+// by one: the arena frees everything when it is destroyed.
+struct Arena {
+    static constexpr size_t kChunk = (size_t)256 << 20;
+    std::vector<void *> chunks;
+    size_t used = 0, cap = 0;       // of the last chunk
+    size_t total = 0;
+    hipError_t alloc(size_t bytes, void **out)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (chunks.empty() || used + bytes > cap) {
+            const size_t want = std::max(bytes, kChunk);
+            void *p = nullptr;
+            hipError_t e = hipMalloc(&p, want);
+            if (e != hipSuccess) return e;
+            chunks.push_back(p);
+            used = 0; cap = want; total += want;
+        }
+        *out = static_cast<char *>(chunks.back()) + used;
+        used += bytes;
+        return hipSuccess;
+    }
+    void release() { for (void *p : chunks) (void)hipFree(p); chunks.clear(); used = cap = total = 0; }
+};
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    Arena *arena = nullptr;      // non-null: slices of the arena (a slice that is outgrown is abandoned)
     hipError_t reserve(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         size_t want = std::max<size_t>(bytes, 256);
+        if (arena) {
+            hipError_t e = arena->alloc(want, &p);
+            cap = e == hipSuccess ? want : 0;
+            return e;
+        }
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && !arena) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Buffers a context needs while it builds (and, for the k-NN facade, after): the caller-order
+// copies of the target and its normals, the cell tables the exact search walks, sort keys,
+// staging.  A context owns one; the members of an arena batch share their batch's, so on them
+// only what the iteration loop needs outlives the set-up calls.
+struct Scratch {
+    DevBuf tgt_aos, nrm_aos, run2, end1;
+    DevBuf tmp_aos, keys_a, keys_b, vals_a, vals_b, marks, ranks, block_of_rank, sort_tmp, bbox6;
+    DevBuf knn_idx, knn_d2, unresolved, n_unres;
+    float *h_small = nullptr;      // pinned: small results on their way back (bounding box, counts)
+    void release()
+    {
+        DevBuf *bufs[] = { &tgt_aos, &nrm_aos, &run2, &end1, &tmp_aos, &keys_a, &keys_b, &vals_a, &vals_b,
+                           &marks, &ranks, &block_of_rank, &sort_tmp, &bbox6, &knn_idx, &knn_d2,
+                           &unresolved, &n_unres };
+        for (DevBuf *b : bufs) b->release();
+        if (h_small) (void)hipHostFree(h_small);
+        h_small = nullptr;
+    }
 };
 
 // an event that is destroyed on every path out of the scope that made it
@@ -107,7 +160,9 @@ struct svicp_ctx {
     bool have_target = false;
     GridDesc g{};
     int nranked = 0;
-    DevBuf tgt_aos, nrm_aos, pts, nrm, dir, run2, end1, quad;
+    DevBuf pts, nrm, dir, quad;
+    Scratch own_scr, *scr = &own_scr;    // (an arena batch points its members at one shared Scratch)
+    bool lean() const { return scr != &own_scr; }
 
     // source
     int64_t n = 0;
@@ -117,15 +172,12 @@ struct svicp_ctx {
     DevBuf st_tp, st_nv, st_lb;   // per source point: matched target point, normal, bound
     DevBuf tile_flags;            // [2][kFlagCap] bytes: which tiles had work in the last two iterations
 
-    // scratch shared by the set-up steps
-    DevBuf tmp_aos, keys_a, keys_b, vals_a, vals_b, marks, ranks, block_of_rank, sort_tmp, bbox6;
-    DevBuf knn_idx, knn_d2, unresolved, n_unres;
 
     // iteration loop
     DevBuf partials, totals, deltas, state, xhist, ihist;
     IcpState *h_state = nullptr;   // pinned and mapped: the kernel that ends a run writes it
     IcpState *h_state_dev = nullptr;
-    float *h_small = nullptr;      // pinned: small results on their way back (bounding box, counts)
+    bool h_state_pinned = false;   // h_state came from hipHostMalloc (a batch member's is plain memory)
     int hist_cap = 0, last_iters = 0;
     int nb = 0, chunk = 0;
     hipGraphExec_t gexec = nullptr;
@@ -156,6 +208,14 @@ struct svicp_ctx {
 
 // Many independent registrations advanced by one launch per iteration.
 struct svicp_batch {
+    // svicp_batch_create_from_arrays: the batch owns its pairs' contexts, one arena for all
+    // their device memory, the scratch they share and one stream
+    bool owns = false;
+    Arena arena;
+    Scratch shared;
+    hipStream_t own_stream = nullptr;
+    std::vector<IcpState> host_states;
+    double setup_ms = 0.0;
     std::vector<svicp_ctx *> ctxs;
     svicp_ctx *lead = nullptr;          // device, stream and error text of the batch
     DevBuf pairs, block_map, states, rt_all;   // rt_all: R, T of every pair for the next launch
@@ -211,7 +271,7 @@ void drop_graph(svicp_ctx *ctx)
 constexpr size_t kSmallBytes = 8192;
 int ensure_small(svicp_ctx *ctx)
 {
-    if (!ctx->h_small) HIPCHK(hipHostMalloc((void **)&ctx->h_small, kSmallBytes, 0));
+    if (!ctx->scr->h_small) HIPCHK(hipHostMalloc((void **)&ctx->scr->h_small, kSmallBytes, 0));
     return SVICP_OK;
 }
 
@@ -219,14 +279,14 @@ int ensure_small(svicp_ctx *ctx)
 int device_bbox(svicp_ctx *ctx, const float *aos, int64_t n, float mn[3], float mx[3])
 {
     const int nblk = 256;
-    HIPCHK(ctx->bbox6.reserve(sizeof(float) * 6 * nblk));
+    HIPCHK(ctx->scr->bbox6.reserve(sizeof(float) * 6 * nblk));
     hipLaunchKernelGGL(bbox_kernel, dim3(nblk), dim3(kBlockThreads), 0, ctx->stream, aos,
-                       (long long)n, ctx->bbox6.as<float>());
+                       (long long)n, ctx->scr->bbox6.as<float>());
     LAUNCHCHK("bbox_kernel");
     int rc = ensure_small(ctx);
     if (rc) return rc;
-    float *h = ctx->h_small;
-    HIPCHK(hipMemcpyAsync(h, ctx->bbox6.p, sizeof(float) * 6 * nblk, hipMemcpyDeviceToHost, ctx->stream));
+    float *h = ctx->scr->h_small;
+    HIPCHK(hipMemcpyAsync(h, ctx->scr->bbox6.p, sizeof(float) * 6 * nblk, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int a = 0; a < 3; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
     for (int b = 0; b < nblk; ++b)
@@ -239,17 +299,17 @@ int device_bbox(svicp_ctx *ctx, const float *aos, int64_t n, float mn[3], float 
 
 int sort_pairs(svicp_ctx *ctx, int64_t count, int bits)
 {
-    HIPCHK(ctx->keys_b.reserve(sizeof(unsigned long long) * count));
-    HIPCHK(ctx->vals_b.reserve(sizeof(int) * count));
+    HIPCHK(ctx->scr->keys_b.reserve(sizeof(unsigned long long) * count));
+    HIPCHK(ctx->scr->vals_b.reserve(sizeof(int) * count));
     size_t bytes = 0;
-    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, ctx->keys_a.as<unsigned long long>(),
-                                     ctx->keys_b.as<unsigned long long>(), ctx->vals_a.as<int>(),
-                                     ctx->vals_b.as<int>(), (size_t)count, 0u, (unsigned)bits,
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, ctx->scr->keys_a.as<unsigned long long>(),
+                                     ctx->scr->keys_b.as<unsigned long long>(), ctx->scr->vals_a.as<int>(),
+                                     ctx->scr->vals_b.as<int>(), (size_t)count, 0u, (unsigned)bits,
                                      ctx->stream));
-    HIPCHK(ctx->sort_tmp.reserve(bytes));
-    HIPCHK(rocprim::radix_sort_pairs(ctx->sort_tmp.p, bytes, ctx->keys_a.as<unsigned long long>(),
-                                     ctx->keys_b.as<unsigned long long>(), ctx->vals_a.as<int>(),
-                                     ctx->vals_b.as<int>(), (size_t)count, 0u, (unsigned)bits,
+    HIPCHK(ctx->scr->sort_tmp.reserve(bytes));
+    HIPCHK(rocprim::radix_sort_pairs(ctx->scr->sort_tmp.p, bytes, ctx->scr->keys_a.as<unsigned long long>(),
+                                     ctx->scr->keys_b.as<unsigned long long>(), ctx->scr->vals_a.as<int>(),
+                                     ctx->scr->vals_b.as<int>(), (size_t)count, 0u, (unsigned)bits,
                                      ctx->stream));
     return SVICP_OK;
 }
@@ -261,11 +321,11 @@ int sort_pairs(svicp_ctx *ctx, int64_t count, int bits)
 int run_knn(svicp_ctx *ctx, const float *q_aos, int64_t n, int k, int *idx, float *d2)
 {
     if (n == 0) return SVICP_OK;
-    HIPCHK(ctx->unresolved.reserve(sizeof(int) * 2 * n));
-    HIPCHK(ctx->n_unres.reserve(sizeof(int) * 2));
-    HIPCHK(hipMemsetAsync(ctx->n_unres.p, 0, sizeof(int) * 2, ctx->stream));
+    HIPCHK(ctx->scr->unresolved.reserve(sizeof(int) * 2 * n));
+    HIPCHK(ctx->scr->n_unres.reserve(sizeof(int) * 2));
+    HIPCHK(hipMemsetAsync(ctx->scr->n_unres.p, 0, sizeof(int) * 2, ctx->stream));
     const int grid = std::min(cdiv(n, kBlockThreads), 65536);
-    int *list = ctx->unresolved.as<int>(), *nlist = ctx->n_unres.as<int>();
+    int *list = ctx->scr->unresolved.as<int>(), *nlist = ctx->scr->n_unres.as<int>();
     int *unres = list + n, *nun = nlist + 1;
     const bool by_wave = k <= kKnnWaveK;
     if (by_wave) {
@@ -300,11 +360,11 @@ int run_knn(svicp_ctx *ctx, const float *q_aos, int64_t n, int k, int *idx, floa
 int run_nn1(svicp_ctx *ctx, bool exact)
 {
     const int64_t n = ctx->n;
-    HIPCHK(ctx->knn_idx.reserve(sizeof(int) * std::max<int64_t>(n, 1)));
-    HIPCHK(ctx->knn_d2.reserve(sizeof(float) * std::max<int64_t>(n, 1)));
+    HIPCHK(ctx->scr->knn_idx.reserve(sizeof(int) * std::max<int64_t>(n, 1)));
+    HIPCHK(ctx->scr->knn_d2.reserve(sizeof(float) * std::max<int64_t>(n, 1)));
     if (n == 0) return SVICP_OK;
-    HIPCHK(ctx->unresolved.reserve(sizeof(int) * n));
-    HIPCHK(ctx->n_unres.reserve(sizeof(int)));
+    HIPCHK(ctx->scr->unresolved.reserve(sizeof(int) * n));
+    HIPCHK(ctx->scr->n_unres.reserve(sizeof(int)));
     const float *x = ctx->cur ? ctx->wx.as<float>() : ctx->sx0.as<float>();
     const float *y = ctx->cur ? ctx->wy.as<float>() : ctx->sy0.as<float>();
     const float *z = ctx->cur ? ctx->wz.as<float>() : ctx->sz0.as<float>();
@@ -313,23 +373,23 @@ int run_nn1(svicp_ctx *ctx, bool exact)
     if (!exact) {
         hipLaunchKernelGGL((nn1_kernel<false, 4>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
                            ctx->g, x, y, z, perm, (int)n, ctx->opt.dist_threshold,
-                           ctx->knn_idx.as<int>(), ctx->knn_d2.as<float>(), (int *)nullptr,
+                           ctx->scr->knn_idx.as<int>(), ctx->scr->knn_d2.as<float>(), (int *)nullptr,
                            (int *)nullptr);
         LAUNCHCHK("nn1_kernel");
     } else {
-        HIPCHK(hipMemsetAsync(ctx->n_unres.p, 0, sizeof(int), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->scr->n_unres.p, 0, sizeof(int), ctx->stream));
         // one chunk of 256 queries per block: the far queries, which take long, come in
         // stretches, and the dispatcher spreads them best when the blocks are small
         const int grid_exact = (int)std::min<int64_t>(cdiv(n, kBlockThreads), 1 << 20);
         hipLaunchKernelGGL((nn1_kernel<true, 4>), dim3(grid_exact), dim3(kBlockThreads), 0, ctx->stream,
                            ctx->g, x, y, z, perm, (int)n, ctx->opt.dist_threshold,
-                           ctx->knn_idx.as<int>(), ctx->knn_d2.as<float>(),
-                           ctx->unresolved.as<int>(), ctx->n_unres.as<int>());
+                           ctx->scr->knn_idx.as<int>(), ctx->scr->knn_d2.as<float>(),
+                           ctx->scr->unresolved.as<int>(), ctx->scr->n_unres.as<int>());
         LAUNCHCHK("nn1_kernel(exact)");
         hipLaunchKernelGGL(nn1_brute_kernel, dim3(std::min<int64_t>(n, 2048)), dim3(kBlockThreads),
-                           0, ctx->stream, ctx->g, x, y, z, perm, ctx->unresolved.as<int>(),
-                           ctx->n_unres.as<int>(), ctx->knn_idx.as<int>(),
-                           ctx->knn_d2.as<float>());
+                           0, ctx->stream, ctx->g, x, y, z, perm, ctx->scr->unresolved.as<int>(),
+                           ctx->scr->n_unres.as<int>(), ctx->scr->knn_idx.as<int>(),
+                           ctx->scr->knn_d2.as<float>());
         LAUNCHCHK("nn1_brute_kernel");
     }
     return SVICP_OK;
@@ -364,6 +424,7 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
     if (!ctx->h_state) {
         HIPCHK(hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState), hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void **)&ctx->h_state_dev, ctx->h_state, 0));
+        ctx->h_state_pinned = true;
     }
     return SVICP_OK;
 }
@@ -595,16 +656,13 @@ int svicp_destroy(svicp_ctx *ctx)
     drop_graph(ctx);
     if (ctx->comm) { (void)rccl_api()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
-    DevBuf *bufs[] = { &ctx->tgt_aos, &ctx->nrm_aos, &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->run2, &ctx->quad,
-                       &ctx->end1, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx, &ctx->wy, &ctx->wz,
-                       &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->tile_flags, &ctx->perm, &ctx->tmp_aos, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a,
-                       &ctx->vals_b, &ctx->marks, &ctx->ranks, &ctx->block_of_rank,
-                       &ctx->sort_tmp, &ctx->bbox6, &ctx->knn_idx, &ctx->knn_d2,
-                       &ctx->unresolved, &ctx->n_unres, &ctx->partials, &ctx->totals, &ctx->deltas, &ctx->state, &ctx->xhist,
-                       &ctx->ihist, &ctx->p2p_sums, &ctx->rthist };
-    for (DevBuf *b : bufs) b->release();
-    if (ctx->h_state) (void)hipHostFree(ctx->h_state);
-    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+    DevBuf *bufs[] = { &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->quad, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx,
+                       &ctx->wy, &ctx->wz, &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->tile_flags, &ctx->perm,
+                       &ctx->partials, &ctx->totals, &ctx->deltas, &ctx->state, &ctx->xhist, &ctx->ihist,
+                       &ctx->p2p_sums, &ctx->rthist };
+    for (DevBuf *b : bufs) b->release();          // (slices of an arena are the arena's to free)
+    ctx->own_scr.release();
+    if (ctx->h_state && ctx->h_state_pinned) (void)hipHostFree(ctx->h_state);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SVICP_OK;
@@ -681,18 +739,18 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
     ctx->m = m;
     const int64_t mm = std::max<int64_t>(m, 1);
 
-    HIPCHK(ctx->tgt_aos.reserve(sizeof(float) * 3 * mm));
-    HIPCHK(ctx->nrm_aos.reserve(sizeof(float) * 3 * mm));
+    HIPCHK(ctx->scr->tgt_aos.reserve(sizeof(float) * 3 * mm));
+    HIPCHK(ctx->scr->nrm_aos.reserve(sizeof(float) * 3 * mm));
     HIPCHK(ctx->pts.reserve(sizeof(float4) * mm));
     HIPCHK(ctx->nrm.reserve(sizeof(float) * 3 * mm));
     if (m > 0)
-        HIPCHK(hipMemcpyAsync(ctx->tgt_aos.p, xyz_aos, sizeof(float) * 3 * m, hipMemcpyHostToDevice,
+        HIPCHK(hipMemcpyAsync(ctx->scr->tgt_aos.p, xyz_aos, sizeof(float) * 3 * m, hipMemcpyHostToDevice,
                               ctx->stream));
 
     // ---- grid geometry ----
     float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
     if (m > 0) {
-        int rc = device_bbox(ctx, ctx->tgt_aos.as<float>(), m, mn, mx);
+        int rc = device_bbox(ctx, ctx->scr->tgt_aos.as<float>(), m, mn, mx);
         if (rc) return rc;
         for (int a = 0; a < 3; ++a)
             if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]))
@@ -732,18 +790,18 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
     nbt = (long long)g.nbx * g.nby * g.nbz;
 
     // ---- sort by cell key ----
-    HIPCHK(ctx->keys_a.reserve(sizeof(unsigned long long) * mm));
-    HIPCHK(ctx->vals_a.reserve(sizeof(int) * mm));
-    HIPCHK(ctx->marks.reserve(sizeof(int) * nbt));
-    HIPCHK(ctx->ranks.reserve(sizeof(int) * nbt));
+    HIPCHK(ctx->scr->keys_a.reserve(sizeof(unsigned long long) * mm));
+    HIPCHK(ctx->scr->vals_a.reserve(sizeof(int) * mm));
+    HIPCHK(ctx->scr->marks.reserve(sizeof(int) * nbt));
+    HIPCHK(ctx->scr->ranks.reserve(sizeof(int) * nbt));
     HIPCHK(ctx->dir.reserve(sizeof(int) * nbt));
-    HIPCHK(ctx->block_of_rank.reserve(sizeof(int) * std::min<long long>(nbt, 8 * mm)));   // a point marks up to 8 blocks
-    HIPCHK(hipMemsetAsync(ctx->marks.p, 0, sizeof(int) * nbt, ctx->stream));
+    HIPCHK(ctx->scr->block_of_rank.reserve(sizeof(int) * std::min<long long>(nbt, 8 * mm)));   // a point marks up to 8 blocks
+    HIPCHK(hipMemsetAsync(ctx->scr->marks.p, 0, sizeof(int) * nbt, ctx->stream));
     int nranked = 0;
     if (m > 0) {
         hipLaunchKernelGGL(cell_key_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, g,
-                           ctx->tgt_aos.as<float>(), (int)m, ctx->keys_a.as<unsigned long long>(),
-                           ctx->vals_a.as<int>());
+                           ctx->scr->tgt_aos.as<float>(), (int)m, ctx->scr->keys_a.as<unsigned long long>(),
+                           ctx->scr->vals_a.as<int>());
         LAUNCHCHK("cell_key_kernel");
         unsigned long long ncell = (unsigned long long)g.nx * g.ny * g.nz;
         int bits = 1;
@@ -751,50 +809,50 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
         int rc = sort_pairs(ctx, m, bits);
         if (rc) return rc;
         hipLaunchKernelGGL(mark_blocks_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, g,
-                           ctx->keys_b.as<unsigned long long>(), (int)m, ctx->marks.as<int>());
+                           ctx->scr->keys_b.as<unsigned long long>(), (int)m, ctx->scr->marks.as<int>());
         LAUNCHCHK("mark_blocks_kernel");
     }
     {
         size_t bytes = 0;
-        HIPCHK(rocprim::exclusive_scan(nullptr, bytes, ctx->marks.as<int>(), ctx->ranks.as<int>(), 0,
+        HIPCHK(rocprim::exclusive_scan(nullptr, bytes, ctx->scr->marks.as<int>(), ctx->scr->ranks.as<int>(), 0,
                                        (size_t)nbt, rocprim::plus<int>(), ctx->stream));
-        HIPCHK(ctx->sort_tmp.reserve(bytes));
-        HIPCHK(rocprim::exclusive_scan(ctx->sort_tmp.p, bytes, ctx->marks.as<int>(),
-                                       ctx->ranks.as<int>(), 0, (size_t)nbt, rocprim::plus<int>(),
+        HIPCHK(ctx->scr->sort_tmp.reserve(bytes));
+        HIPCHK(rocprim::exclusive_scan(ctx->scr->sort_tmp.p, bytes, ctx->scr->marks.as<int>(),
+                                       ctx->scr->ranks.as<int>(), 0, (size_t)nbt, rocprim::plus<int>(),
                                        ctx->stream));
         int rc = ensure_small(ctx);
         if (rc) return rc;
-        int *last = reinterpret_cast<int *>(ctx->h_small);     // {last rank, last mark}
-        HIPCHK(hipMemcpyAsync(&last[0], ctx->ranks.as<int>() + (nbt - 1), sizeof(int),
+        int *last = reinterpret_cast<int *>(ctx->scr->h_small);     // {last rank, last mark}
+        HIPCHK(hipMemcpyAsync(&last[0], ctx->scr->ranks.as<int>() + (nbt - 1), sizeof(int),
                               hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(&last[1], ctx->marks.as<int>() + (nbt - 1), sizeof(int),
+        HIPCHK(hipMemcpyAsync(&last[1], ctx->scr->marks.as<int>() + (nbt - 1), sizeof(int),
                               hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         nranked = last[0] + last[1];
     }
     ctx->nranked = nranked;
     hipLaunchKernelGGL(finish_dir_kernel, dim3(cdiv(nbt, 256)), dim3(256), 0, ctx->stream,
-                       ctx->marks.as<int>(), ctx->ranks.as<int>(), (int)nbt, ctx->dir.as<int>(),
-                       ctx->block_of_rank.as<int>());
+                       ctx->scr->marks.as<int>(), ctx->scr->ranks.as<int>(), (int)nbt, ctx->dir.as<int>(),
+                       ctx->scr->block_of_rank.as<int>());
     LAUNCHCHK("finish_dir_kernel");
-    HIPCHK(ctx->run2.reserve(sizeof(uint2) * 64 * std::max(nranked, 1)));
-    HIPCHK(ctx->end1.reserve(sizeof(unsigned) * 64 * std::max(nranked, 1)));
+    HIPCHK(ctx->scr->run2.reserve(sizeof(uint2) * 64 * std::max(nranked, 1)));
+    HIPCHK(ctx->scr->end1.reserve(sizeof(unsigned) * 64 * std::max(nranked, 1)));
     HIPCHK(ctx->quad.reserve(sizeof(uint4) * 2 * 64 * std::max(nranked, 1)));
     if (nranked > 0) {
         hipLaunchKernelGGL(fill_cells_kernel, dim3(cdiv((long long)nranked * 64, 256)), dim3(256), 0,
-                           ctx->stream, g, ctx->keys_b.as<unsigned long long>(), (int)m,
-                           ctx->block_of_rank.as<int>(), nranked, ctx->run2.as<uint2>(),
-                           ctx->end1.as<unsigned>());
+                           ctx->stream, g, ctx->scr->keys_b.as<unsigned long long>(), (int)m,
+                           ctx->scr->block_of_rank.as<int>(), nranked, ctx->scr->run2.as<uint2>(),
+                           ctx->scr->end1.as<unsigned>());
         LAUNCHCHK("fill_cells_kernel");
         g.dir = ctx->dir.as<int>();
         hipLaunchKernelGGL(fill_quads_kernel, dim3(cdiv((long long)nranked * 64, 256)), dim3(256), 0,
-                           ctx->stream, g, ctx->block_of_rank.as<int>(), nranked,
-                           ctx->run2.as<uint2>(), ctx->quad.as<uint4>());
+                           ctx->stream, g, ctx->scr->block_of_rank.as<int>(), nranked,
+                           ctx->scr->run2.as<uint2>(), ctx->quad.as<uint4>());
         LAUNCHCHK("fill_quads_kernel");
     }
     g.dir = ctx->dir.as<int>();
-    g.run2 = ctx->run2.as<uint2>();
-    g.end1 = ctx->end1.as<unsigned>();
+    g.run2 = ctx->scr->run2.as<uint2>();
+    g.end1 = ctx->scr->end1.as<unsigned>();
     g.quad = ctx->quad.as<uint4>();
     g.pts = ctx->pts.as<float4>();
     g.nrm = ctx->nrm.as<float>();
@@ -802,27 +860,27 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
 
     if (m > 0) {
         hipLaunchKernelGGL(gather_target_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream,
-                           ctx->tgt_aos.as<float>(), (const float *)nullptr, ctx->vals_b.as<int>(),
+                           ctx->scr->tgt_aos.as<float>(), (const float *)nullptr, ctx->scr->vals_b.as<int>(),
                            (int)m, ctx->pts.as<float4>(), ctx->nrm.as<float>());
         LAUNCHCHK("gather_target_kernel");
         // ---- normals ----
         if (normals_aos) {
-            HIPCHK(hipMemcpyAsync(ctx->nrm_aos.p, normals_aos, sizeof(float) * 3 * m,
+            HIPCHK(hipMemcpyAsync(ctx->scr->nrm_aos.p, normals_aos, sizeof(float) * 3 * m,
                                   hipMemcpyHostToDevice, ctx->stream));
         } else {
             const int k = ctx->opt.normals_k;
-            HIPCHK(ctx->knn_idx.reserve(sizeof(int) * m * k));
-            HIPCHK(ctx->knn_d2.reserve(sizeof(float) * m * k));
-            int rc = run_knn(ctx, ctx->tgt_aos.as<float>(), m, k, ctx->knn_idx.as<int>(),
-                             ctx->knn_d2.as<float>());
+            HIPCHK(ctx->scr->knn_idx.reserve(sizeof(int) * m * k));
+            HIPCHK(ctx->scr->knn_d2.reserve(sizeof(float) * m * k));
+            int rc = run_knn(ctx, ctx->scr->tgt_aos.as<float>(), m, k, ctx->scr->knn_idx.as<int>(),
+                             ctx->scr->knn_d2.as<float>());
             if (rc) return rc;
             hipLaunchKernelGGL(normals_kernel, dim3(cdiv(m, kBlockThreads)), dim3(kBlockThreads), 0,
-                               ctx->stream, ctx->tgt_aos.as<float>(), ctx->knn_idx.as<int>(), (int)m,
-                               k, ctx->nrm_aos.as<float>());
+                               ctx->stream, ctx->scr->tgt_aos.as<float>(), ctx->scr->knn_idx.as<int>(), (int)m,
+                               k, ctx->scr->nrm_aos.as<float>());
             LAUNCHCHK("normals_kernel");
         }
         hipLaunchKernelGGL(gather_target_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream,
-                           ctx->tgt_aos.as<float>(), ctx->nrm_aos.as<float>(), ctx->vals_b.as<int>(),
+                           ctx->scr->tgt_aos.as<float>(), ctx->scr->nrm_aos.as<float>(), ctx->scr->vals_b.as<int>(),
                            (int)m, ctx->pts.as<float4>(), ctx->nrm.as<float>());
         LAUNCHCHK("gather_target_kernel(normals)");
     }
@@ -835,9 +893,10 @@ int svicp_get_normals(svicp_ctx *ctx, float *normals_aos_out)
 {
     if (!ctx || !normals_aos_out) return fail(ctx, SVICP_ERR_ARG, "svicp_get_normals: NULL argument");
     if (!ctx->have_target) return fail(ctx, SVICP_ERR_ARG, "svicp_get_normals: no target set");
+    if (ctx->lean()) return fail(ctx, SVICP_ERR_ARG, "svicp_get_normals: not kept for a pair of an arena batch");
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->m > 0)
-        HIPCHK(hipMemcpyAsync(normals_aos_out, ctx->nrm_aos.p, sizeof(float) * 3 * ctx->m,
+        HIPCHK(hipMemcpyAsync(normals_aos_out, ctx->scr->nrm_aos.p, sizeof(float) * 3 * ctx->m,
                               hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SVICP_OK;
@@ -869,27 +928,27 @@ int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n)
         HIPCHK(ctx->st_nv.reserve(sizeof(Float3) * nn));
         if (ctx->st_tp.p != before_tp || ctx->st_nv.p != before_nv) drop_graph(ctx);
     }
-    HIPCHK(ctx->tmp_aos.reserve(sizeof(float) * 3 * nn));
+    HIPCHK(ctx->scr->tmp_aos.reserve(sizeof(float) * 3 * nn));
     ctx->n = n;
     ctx->cur = 0;
     ctx->sorted = false;
     if (n > 0) {
-        HIPCHK(hipMemcpyAsync(ctx->tmp_aos.p, xyz_aos, sizeof(float) * 3 * n, hipMemcpyHostToDevice,
+        HIPCHK(hipMemcpyAsync(ctx->scr->tmp_aos.p, xyz_aos, sizeof(float) * 3 * n, hipMemcpyHostToDevice,
                               ctx->stream));
         const int *perm = nullptr;
         if (ctx->opt.sort_source && n > 1) {
             float mn[3], mx[3];
-            int rc = device_bbox(ctx, ctx->tmp_aos.as<float>(), n, mn, mx);
+            int rc = device_bbox(ctx, ctx->scr->tmp_aos.as<float>(), n, mn, mx);
             if (rc) return rc;
             float ext = 0.f;
             for (int a = 0; a < 3; ++a) ext = std::max(ext, mx[a] - mn[a]);
             if (std::isfinite(ext) && ext > 0.f) {
-                HIPCHK(ctx->keys_a.reserve(sizeof(unsigned long long) * nn));
-                HIPCHK(ctx->vals_a.reserve(sizeof(int) * nn));
+                HIPCHK(ctx->scr->keys_a.reserve(sizeof(unsigned long long) * nn));
+                HIPCHK(ctx->scr->vals_a.reserve(sizeof(int) * nn));
                 hipLaunchKernelGGL(morton_key_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
-                                   ctx->tmp_aos.as<float>(), (int)n, mn[0], mn[1], mn[2],
-                                   2097151.0f / ext, ctx->keys_a.as<unsigned long long>(),
-                                   ctx->vals_a.as<int>());
+                                   ctx->scr->tmp_aos.as<float>(), (int)n, mn[0], mn[1], mn[2],
+                                   2097151.0f / ext, ctx->scr->keys_a.as<unsigned long long>(),
+                                   ctx->scr->vals_a.as<int>());
                 LAUNCHCHK("morton_key_kernel");
                 rc = sort_pairs(ctx, n, 63);
                 if (rc) return rc;
@@ -897,14 +956,14 @@ int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n)
                 HIPCHK(ctx->perm.reserve(sizeof(int) * nn));
                 if (ctx->perm.p != before) drop_graph(ctx);
                 hipLaunchKernelGGL(deal_tiles_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
-                                   ctx->vals_b.as<int>(), (int)n, ctx->perm.as<int>());
+                                   ctx->scr->vals_b.as<int>(), (int)n, ctx->perm.as<int>());
                 LAUNCHCHK("deal_tiles_kernel");
                 perm = ctx->perm.as<int>();
                 ctx->sorted = true;
             }
         }
         hipLaunchKernelGGL(aos_to_soa_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
-                           ctx->tmp_aos.as<float>(), perm, (int)n, ctx->sx0.as<float>(),
+                           ctx->scr->tmp_aos.as<float>(), perm, (int)n, ctx->sx0.as<float>(),
                            ctx->sy0.as<float>(), ctx->sz0.as<float>());
         LAUNCHCHK("aos_to_soa_kernel");
     }
@@ -925,9 +984,9 @@ int svicp_get_source(svicp_ctx *ctx, float *xyz_aos_out)
         const float *z = ctx->cur ? ctx->wz.as<float>() : ctx->sz0.as<float>();
         hipLaunchKernelGGL(soa_to_aos_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, x, y, z,
                            ctx->sorted ? ctx->perm.as<int>() : (const int *)nullptr, (int)n,
-                           ctx->tmp_aos.as<float>());
+                           ctx->scr->tmp_aos.as<float>());
         LAUNCHCHK("soa_to_aos_kernel");
-        HIPCHK(hipMemcpyAsync(xyz_aos_out, ctx->tmp_aos.p, sizeof(float) * 3 * n,
+        HIPCHK(hipMemcpyAsync(xyz_aos_out, ctx->scr->tmp_aos.p, sizeof(float) * 3 * n,
                               hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1097,9 +1156,9 @@ int svicp_correspondences(svicp_ctx *ctx, int32_t *idx_out, float *d2_out)
     int rc = run_nn1(ctx, false);
     if (rc) return rc;
     if (ctx->n > 0) {
-        HIPCHK(hipMemcpyAsync(idx_out, ctx->knn_idx.p, sizeof(int) * ctx->n, hipMemcpyDeviceToHost,
+        HIPCHK(hipMemcpyAsync(idx_out, ctx->scr->knn_idx.p, sizeof(int) * ctx->n, hipMemcpyDeviceToHost,
                               ctx->stream));
-        HIPCHK(hipMemcpyAsync(d2_out, ctx->knn_d2.p, sizeof(float) * ctx->n, hipMemcpyDeviceToHost,
+        HIPCHK(hipMemcpyAsync(d2_out, ctx->scr->knn_d2.p, sizeof(float) * ctx->n, hipMemcpyDeviceToHost,
                               ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1113,20 +1172,21 @@ int svicp_knn(svicp_ctx *ctx, const float *query_aos, int64_t n, int k, int32_t 
     if (n < 0 || k < 1 || (n > 0 && (!query_aos || !idx_out || !d2_out)))
         return fail(ctx, SVICP_ERR_ARG, "svicp_knn: bad argument");
     if (!ctx->have_target) return fail(ctx, SVICP_ERR_ARG, "svicp_knn: no target set");
+    if (ctx->lean()) return fail(ctx, SVICP_ERR_ARG, "svicp_knn: the cell tables are not kept for a pair of an arena batch");
     if (k > 128) k = 128;   // CKNNSearch::setKCount clamps the same way
     if (n == 0) return SVICP_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(ctx->tmp_aos.reserve(sizeof(float) * 3 * n));
-    HIPCHK(ctx->knn_idx.reserve(sizeof(int) * n * k));
-    HIPCHK(ctx->knn_d2.reserve(sizeof(float) * n * k));
-    HIPCHK(hipMemcpyAsync(ctx->tmp_aos.p, query_aos, sizeof(float) * 3 * n, hipMemcpyHostToDevice,
+    HIPCHK(ctx->scr->tmp_aos.reserve(sizeof(float) * 3 * n));
+    HIPCHK(ctx->scr->knn_idx.reserve(sizeof(int) * n * k));
+    HIPCHK(ctx->scr->knn_d2.reserve(sizeof(float) * n * k));
+    HIPCHK(hipMemcpyAsync(ctx->scr->tmp_aos.p, query_aos, sizeof(float) * 3 * n, hipMemcpyHostToDevice,
                           ctx->stream));
-    int rc = run_knn(ctx, ctx->tmp_aos.as<float>(), n, k, ctx->knn_idx.as<int>(),
-                     ctx->knn_d2.as<float>());
+    int rc = run_knn(ctx, ctx->scr->tmp_aos.as<float>(), n, k, ctx->scr->knn_idx.as<int>(),
+                     ctx->scr->knn_d2.as<float>());
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(idx_out, ctx->knn_idx.p, sizeof(int) * n * k, hipMemcpyDeviceToHost,
+    HIPCHK(hipMemcpyAsync(idx_out, ctx->scr->knn_idx.p, sizeof(int) * n * k, hipMemcpyDeviceToHost,
                           ctx->stream));
-    HIPCHK(hipMemcpyAsync(d2_out, ctx->knn_d2.p, sizeof(float) * n * k, hipMemcpyDeviceToHost,
+    HIPCHK(hipMemcpyAsync(d2_out, ctx->scr->knn_d2.p, sizeof(float) * n * k, hipMemcpyDeviceToHost,
                           ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SVICP_OK;
@@ -1349,6 +1409,8 @@ int svicp_time_nn(svicp_ctx *ctx, int exact, int reps, double *avg_ms)
     if (!ctx || !avg_ms || reps < 1) return fail(ctx, SVICP_ERR_ARG, "svicp_time_nn: bad argument");
     if (!ctx->have_target || !ctx->have_source)
         return fail(ctx, SVICP_ERR_ARG, "svicp_time_nn: set the target and the source first");
+    if (ctx->lean() && exact)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_time_nn: the cell tables are not kept for a pair of an arena batch");
     HIPCHK(hipSetDevice(ctx->device));
     ScopedEvent a, b;
     HIPCHK(a.create());
@@ -1376,13 +1438,13 @@ int svicp_time_gather(svicp_ctx *ctx, int real_addresses, int per_query, int rep
     if (!ctx->have_target || !ctx->have_source || ctx->n == 0 || ctx->m == 0)
         return fail(ctx, SVICP_ERR_ARG, "svicp_time_gather: set a non-empty target and source first");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(ctx->n_unres.reserve(sizeof(unsigned long long) * 2));
+    HIPCHK(ctx->scr->n_unres.reserve(sizeof(unsigned long long) * 2));
     const int64_t n = ctx->n;
     const float *x = ctx->cur ? ctx->wx.as<float>() : ctx->sx0.as<float>();
     const float *y = ctx->cur ? ctx->wy.as<float>() : ctx->sy0.as<float>();
     const float *z = ctx->cur ? ctx->wz.as<float>() : ctx->sz0.as<float>();
     const int grid = std::min(cdiv(n, kBlockThreads), ctx->num_cus * 8);
-    unsigned long long *cnt = ctx->n_unres.as<unsigned long long>();
+    unsigned long long *cnt = ctx->scr->n_unres.as<unsigned long long>();
     auto launch = [&](unsigned long long *count) {
         if (real_addresses)
             hipLaunchKernelGGL((gather_probe_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
@@ -1403,13 +1465,13 @@ int svicp_time_gather(svicp_ctx *ctx, int real_addresses, int per_query, int rep
     HIPCHK(hipEventRecord(b.ev, ctx->stream));
     int rc = ensure_small(ctx);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->h_small, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->scr->h_small, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, a.ev, b.ev));
     *avg_ms = (double)ms / reps;
     if (wave_instructions)
-        *wave_instructions = (double)*reinterpret_cast<unsigned long long *>(ctx->h_small);
+        *wave_instructions = (double)*reinterpret_cast<unsigned long long *>(ctx->scr->h_small);
     return SVICP_OK;
 }
 
@@ -1538,12 +1600,109 @@ int svicp_batch_create(svicp_ctx **ctxs, int count, svicp_batch **out)
 int svicp_batch_destroy(svicp_batch *b)
 {
     if (!b) return SVICP_OK;
-    (void)hipSetDevice(b->lead->device);
-    (void)hipStreamSynchronize(b->lead->stream);
+    if (b->lead) {
+        (void)hipSetDevice(b->lead->device);
+        (void)hipStreamSynchronize(b->lead->stream);
+    }
     if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
     b->pairs.release(); b->block_map.release(); b->states.release(); b->rt_all.release();
     if (b->h_states) (void)hipHostFree(b->h_states);
+    if (b->owns) {
+        for (svicp_ctx *c : b->ctxs) {
+            c->own_stream = nullptr;        // the batch's stream, destroyed below
+            (void)svicp_destroy(c);
+        }
+        b->shared.release();
+        b->arena.release();
+        if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+    }
     delete b;
+    return SVICP_OK;
+}
+
+int svicp_batch_create_from_arrays(int device_id, int count, const int64_t *tgt_offsets,
+                                   const float *tgt_xyz, const float *tgt_normals,
+                                   const int64_t *src_offsets, const float *src_xyz,
+                                   const svicp_options *opt, svicp_batch **out)
+{
+    if (!out) return SVICP_ERR_ARG;
+    *out = nullptr;
+    if (count < 1 || !tgt_offsets || !tgt_xyz || !src_offsets || !src_xyz)
+        return fail(nullptr, SVICP_ERR_ARG, "svicp_batch_create_from_arrays: bad argument");
+    for (int i = 0; i < count; ++i)
+        if (tgt_offsets[i + 1] < tgt_offsets[i] || src_offsets[i + 1] < src_offsets[i] || tgt_offsets[0] < 0 ||
+            src_offsets[0] < 0)
+            return fail(nullptr, SVICP_ERR_ARG, "svicp_batch_create_from_arrays: offsets must not decrease");
+    // the first pair's context is made the usual way (device checks, the workspace address);
+    // the others copy its device facts and share its stream
+    svicp_ctx *first = nullptr;
+    int rc = svicp_create(device_id, &first);
+    if (rc) return rc;
+    svicp_batch *b = new svicp_batch();
+    b->owns = true;
+    b->own_stream = first->own_stream;
+    b->host_states.resize(count);
+    b->ctxs.reserve(count);
+    const auto t_begin = std::chrono::steady_clock::now();
+    for (int i = 0; i < count && rc == SVICP_OK; ++i) {
+        svicp_ctx *c = first;
+        if (i > 0) {
+            c = new svicp_ctx();
+            c->device = first->device;
+            c->num_cus = first->num_cus;
+            c->enq_scratch = first->enq_scratch;
+            c->own_stream = nullptr;
+            c->stream = b->own_stream;
+        }
+        if (opt) c->opt = *opt; else svicp_default_options(&c->opt);
+        c->scr = &b->shared;
+        DevBuf *persistent[] = { &c->pts, &c->nrm, &c->dir, &c->quad, &c->sx0, &c->sy0, &c->sz0, &c->wx, &c->wy,
+                                 &c->wz, &c->st_tp, &c->st_nv, &c->st_lb, &c->tile_flags, &c->perm, &c->partials,
+                                 &c->totals, &c->deltas, &c->state, &c->xhist, &c->ihist, &c->p2p_sums,
+                                 &c->rthist };
+        for (DevBuf *d : persistent) d->arena = &b->arena;
+        c->h_state = &b->host_states[i];
+        c->h_state_pinned = false;
+        b->ctxs.push_back(c);
+        if (!(c->opt.dist_threshold > 0.f) || c->opt.normals_k < 3 || c->opt.normals_k > 128) {
+            rc = fail(c, SVICP_ERR_ARG, "svicp_batch_create_from_arrays: bad options");
+            break;
+        }
+        const int64_t m = tgt_offsets[i + 1] - tgt_offsets[i], n = src_offsets[i + 1] - src_offsets[i];
+        rc = svicp_set_target(c, tgt_xyz + 3 * tgt_offsets[i], m,
+                              tgt_normals ? tgt_normals + 3 * tgt_offsets[i] : nullptr);
+        if (rc == SVICP_OK) rc = svicp_set_source(c, src_xyz + 3 * src_offsets[i], n);
+        if (rc == SVICP_OK) rc = ensure_iteration_buffers(c, 64);
+        if (rc != SVICP_OK) g_create_error = "pair " + std::to_string(i) + ": " + c->err;
+    }
+    if (rc == SVICP_OK && hipStreamSynchronize(b->own_stream) != hipSuccess)
+        rc = fail(nullptr, SVICP_ERR_HIP, "svicp_batch_create_from_arrays: hipStreamSynchronize");
+    if (rc != SVICP_OK) {
+        b->lead = b->ctxs.empty() ? nullptr : b->ctxs[0];
+        const std::string keep = g_create_error;
+        (void)svicp_batch_destroy(b);
+        g_create_error = keep;
+        return rc;
+    }
+    b->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    b->lead = b->ctxs[0];
+    *out = b;
+    return SVICP_OK;
+}
+
+int svicp_batch_info(const svicp_batch *b, int *count, double *setup_ms, double *device_bytes)
+{
+    if (!b) return SVICP_ERR_ARG;
+    if (count) *count = (int)b->ctxs.size();
+    if (setup_ms) *setup_ms = b->setup_ms;
+    if (device_bytes) *device_bytes = (double)b->arena.total;
+    return SVICP_OK;
+}
+
+int svicp_batch_pair(svicp_batch *b, int index, svicp_ctx **ctx_out)
+{
+    if (!b || !ctx_out || index < 0 || index >= (int)b->ctxs.size()) return SVICP_ERR_ARG;
+    *ctx_out = b->ctxs[index];
     return SVICP_OK;
 }
 
@@ -1571,7 +1730,7 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
         if (rc) { ctx->err = c->err; return rc; }
         // the pair's set-up work (and any clearing of fresh buffers just queued) ran on its
         // own stream: it must be complete before the batch's stream touches the buffers
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->stream != ctx->stream) HIPCHK(hipStreamSynchronize(c->stream));
         const float thr = c->opt.dist_threshold;
         BatchPair &P = hp[i];
         P.g = c->g;

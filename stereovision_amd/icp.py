@@ -49,9 +49,19 @@ class Context:
         if rc != 0:
             raise SvicpError(rc, self._lib.svicp_last_error(self._h).decode())
 
+    @classmethod
+    def _borrowed(cls, lib, handle):
+        """A view of a context that something else owns (a pair of an ArenaBatch)."""
+        self = cls.__new__(cls)
+        self._lib = lib
+        self._h = handle
+        self._is_borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            self._lib.svicp_destroy(self._h)
+            if not getattr(self, "_is_borrowed", False):
+                self._lib.svicp_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -300,6 +310,62 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class ArenaBatch(Batch):
+    """svicp_batch_create_from_arrays: hundreds of pairs from flat arrays, one stream and one
+    arena of device memory for all of them.  targets / normals / sources: lists of (n_i, 3)
+    float32 arrays (normals may be None: estimated per pair)."""
+
+    def __init__(self, targets, normals, sources, device=0, **options):
+        self._lib = _lib.load()
+        self.contexts = []
+        count = len(targets)
+        assert count >= 1 and len(sources) == count and (normals is None or len(normals) == count)
+        t_off = np.zeros(count + 1, np.int64)
+        s_off = np.zeros(count + 1, np.int64)
+        t_off[1:] = np.cumsum([len(t) for t in targets])
+        s_off[1:] = np.cumsum([len(s) for s in sources])
+        tgt = np.ascontiguousarray(np.concatenate([_cloud(t, "target") for t in targets]))
+        src = np.ascontiguousarray(np.concatenate([_cloud(s, "source") for s in sources]))
+        nrm = None if normals is None else np.ascontiguousarray(
+            np.concatenate([_cloud(n, "normals") for n in normals]))
+        assert nrm is None or nrm.shape == tgt.shape
+        o = Options()
+        self._lib.svicp_default_options(C.byref(o))
+        for k, val in options.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k!r}")
+            setattr(o, k, val)
+        i64 = C.POINTER(C.c_int64)
+        self._h = C.c_void_p()
+        rc = self._lib.svicp_batch_create_from_arrays(
+            int(device), count, t_off.ctypes.data_as(i64), _fp(tgt), _fp(nrm) if nrm is not None else None,
+            s_off.ctypes.data_as(i64), _fp(src), C.byref(o), C.byref(self._h))
+        if rc != 0:
+            raise SvicpError(rc, self._lib.svicp_last_error(None).decode())
+        self.count = count
+
+    def pair(self, index):
+        """Pair `index`'s context, on loan: get_source, history, correspondences."""
+        h = C.c_void_p()
+        if self._lib.svicp_batch_pair(self._h, int(index), C.byref(h)) != 0:
+            raise IndexError(index)
+        return Context._borrowed(self._lib, h)
+
+    def info(self):
+        """(pairs, set-up ms on the host, bytes of device memory in the arena)."""
+        n, ms, by = C.c_int(), C.c_double(), C.c_double()
+        self._lib.svicp_batch_info(self._h, C.byref(n), C.byref(ms), C.byref(by))
+        return n.value, ms.value, by.value
+
+    def run(self, iterations):
+        T = np.empty((self.count, 16), np.float64)
+        infos = (Info * self.count)()
+        rc = self._lib.svicp_batch_run(self._h, int(iterations), _dp(T), infos)
+        if rc != 0:
+            raise SvicpError(rc, self._lib.svicp_batch_last_error(self._h).decode())
+        return T.reshape(self.count, 4, 4), list(infos)
 
 
 class CKNNSearch:

@@ -603,3 +603,76 @@ def test_default_stream_runs_without_capture(ctx, synth32):
     assert info.status == 0
     assert np.abs(T_null - T_own).max() < 1e-10 and np.abs(T_again - T_own).max() < 1e-10
     assert np.abs(Tp_null - Tp_own).max() < 1e-9
+
+
+def test_arena_batch_equals_one_by_one(po):
+    """svicp_batch_create_from_arrays on ragged pairs: every pair's result equals its own
+    svicp_run and the oracle; borrowed contexts give the moved source and the history."""
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+    sides = [48, 96, 33, 64, 80]
+    T_one, tg, nr, sr = [], [], [], []
+    for i, side in enumerate(sides):
+        t, n, s, _ = synth.make_pair(side, pair=10 + i, pose=synth.small_pose(i))
+        s = s[: len(s) - 7 * i]                        # ragged sources
+        tg.append(t); nr.append(n); sr.append(s)
+        with sv.Context(0) as c:
+            c.set_target(t, n)
+            c.set_source(s)
+            T, info = c.run(9)
+            T_one.append((T, info.inliers, c.get_source(), c.history()[0]))
+    batch = sv.ArenaBatch(tg, nr, sr)
+    assert batch.info()[0] == len(sides) and batch.info()[2] > 0
+    for rep in range(2):                               # the second run replays the graph
+        Ts, infos = batch.run(9)
+        for i in range(len(sides)):
+            assert np.abs(Ts[i] - T_one[i][0]).max() < 1e-10
+            assert infos[i].inliers == T_one[i][1] and infos[i].status == 0
+    for i in (0, 3):
+        c = batch.pair(i)
+        assert np.array_equal(c.get_source(), T_one[i][2])
+        assert np.abs(c.history()[0] - T_one[i][3]).max() < 1e-10
+        with pytest.raises(sv.SvicpError):
+            c.knn(sr[i][:4], 1)                        # the exact-search tables are not kept
+        c.close()                                      # a borrowed context: nothing is destroyed
+    r = po.icp_point2plane(po.KDTree(tg[1]), nr[1], sr[1], 9)
+    assert np.abs(Ts[1] - r["trans"]).max() < 1e-8
+    batch.close()
+    # normals estimated per pair when none are given
+    b2 = sv.ArenaBatch(tg[:2], None, sr[:2])
+    T2, _ = b2.run(5)
+    with sv.Context(0) as c:
+        c.set_target(tg[1]); c.set_source(sr[1])
+        assert np.abs(T2[1] - c.run(5)[0]).max() < 1e-10
+    b2.close()
+    with pytest.raises(sv.SvicpError):
+        sv.ArenaBatch(tg[:1], nr[:1], sr[:1], dist_threshold=-1.0)
+
+
+def test_config4_slice_512_pairs_of_65536_points(po):
+    """The per-GPU slice of the batched configuration at its stated size: 512 independent pairs
+    of 65536 points, 30 iterations, one arena.  Every pair recovers its generating pose (a
+    property that holds at any size); three sampled pairs against the oracle."""
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+    count, side, iters = 512, 256, 30
+    tg, nr, sr, poses = [], [], [], []
+    for i in range(count):
+        t, n, s, P = synth.make_pair(side, pair=i, pose=synth.small_pose(i))
+        tg.append(t); nr.append(n); sr.append(s); poses.append(P)
+    batch = sv.ArenaBatch(tg, nr, sr)
+    Ts, infos = batch.run(iters)
+    ms_first = batch.last_ms()
+    Ts, infos = batch.run(iters)
+    n, setup_ms, dev_bytes = batch.info()
+    print(f"512 x 65536 points, 30 iterations: set-up {setup_ms:.0f} ms, run {batch.last_ms():.2f} ms "
+          f"(first {ms_first:.2f}), arena {dev_bytes / 2**30:.2f} GiB")
+    for i in range(count):
+        assert infos[i].status == 0 and infos[i].inliers > 0.9 * side * side
+        E = Ts[i] @ poses[i]                           # the transform undoes the generating pose
+        assert refmath.rot_angle(E[:3, :3], np.eye(3)) < 2e-4
+        assert np.abs(E[:3, 3]).max() < 0.05
+    for i in (0, 255, 511):
+        r = po.icp_point2plane(po.KDTree(tg[i]), nr[i], sr[i], iters, threads=po.max_threads(), history=False)
+        assert np.abs(Ts[i] - r["trans"]).max() < 1e-8
+    batch.close()

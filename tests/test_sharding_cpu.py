@@ -224,3 +224,66 @@ def test_calibration_views_split_over_two_ranks(po, tmp_path):
     xw, ew = lm_refine(Whole(), start, 5, max_iter=4, host_solve=True)
     assert float(parts[0]["err"]) == pytest.approx(ew, rel=1e-6)
     assert np.abs(parts[0]["x"] - xw).max() < 1e-6 * np.abs(xw).max()
+
+
+# ---- batches of independent pairs split over the ranks --------------------------
+class OracleBatchEngine:
+    """CPU engine for run_pairs_split: the oracle on each of this rank's pairs."""
+
+    def __init__(self, po, pairs):
+        self.po, self.pairs = po, pairs
+
+    def run(self, iterations):
+        T, info = [], []
+        for tgt, nrm, src in self.pairs:
+            r = self.po.icp_point2plane(self.po.KDTree(tgt), nrm, src, iterations)
+            T.append(r["trans"])
+            info.append([0.0, r["info"][-1, 0]])
+        return np.array(T).reshape(-1, 4, 4), np.array(info).reshape(-1, 2)
+
+
+def _make_pairs(count):
+    from stereovision_amd import synth
+    out = []
+    for i in range(count):
+        t, n, s, _ = synth.make_pair(24 + 4 * (i % 3), pair=i, pose=synth.small_pose(i))
+        out.append((t, n, s))
+    return out
+
+
+def _batch_worker(rank, world, port, out_dir, count):
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as po
+    from stereovision_amd.batched import pair_bounds, run_pairs_split
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, last = pair_bounds(count, world, rank)
+    eng = OracleBatchEngine(po, _make_pairs(count)[first:last])
+    T, info = run_pairs_split(eng, count, 3)
+    np.save(os.path.join(out_dir, f"BT{rank}.npy"), T)
+    np.save(os.path.join(out_dir, f"BI{rank}.npy"), info)
+    dist.destroy_process_group()
+
+
+def test_pair_bounds_split_every_pair_once():
+    from stereovision_amd.batched import pair_bounds
+    for count in (0, 1, 5, 512, 4096):
+        for w in (1, 2, 3, 8):
+            spans = [pair_bounds(count, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == count
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(l - f for f, l in spans) - min(l - f for f, l in spans) <= 1
+    assert pair_bounds(4096, 8, 3) == (1536, 2048)       # 512 pairs per GPU
+
+
+def test_pairs_split_over_two_ranks_are_gathered_in_order(po, tmp_path):
+    count = 5                                             # an odd count: ranks get 2 and 3 pairs
+    port = _free_port()
+    mp.spawn(_batch_worker, args=(2, port, str(tmp_path), count), nprocs=2, join=True)
+    T0, T1 = np.load(tmp_path / "BT0.npy"), np.load(tmp_path / "BT1.npy")
+    assert T0.shape == (count, 4, 4) and np.array_equal(T0, T1)
+    assert np.array_equal(np.load(tmp_path / "BI0.npy"), np.load(tmp_path / "BI1.npy"))
+    for i, (t, n, s) in enumerate(_make_pairs(count)):
+        r = po.icp_point2plane(po.KDTree(t), n, s, 3)
+        assert np.array_equal(T0[i], r["trans"])
