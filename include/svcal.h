@@ -78,6 +78,16 @@ int svcal_fetch(svcal_ctx *ctx, svcal_blocks *out);
  * the other ranks are not here: svcal_solve_begin / svcal_solve_end below). */
 int svcal_solve_damped(svcal_ctx *ctx, double lam, double *step_out, double *predicted_out);
 
+/* The `update_intrinsics` argument of doStereoCalibrate (CStereoCameraCalibration.h:24-28).
+ * 1 (the default; what Test/demo.cpp:198 passes): every parameter is refined.  0: the
+ * Jacobian the reference builds holds only the views' and the pose's columns
+ * (CStereoCameraCalibration.cpp:187-245, applied at offset 8 + 2 k, :284-285, :306): the
+ * steps of svcal_solve_damped and svcal_solve_end then leave the 2 (4 + k) intrinsic and
+ * distortion parameters where they are (their entries of step_out are exactly 0) and solve
+ * each view's 6 x 6 block and the pose's 6 x 6 block on their own (the blocks that couple
+ * them with the intrinsics drop out of A).  The evaluation itself does not change. */
+int svcal_set_update_intrinsics(svcal_ctx *ctx, int update_intrinsics);
+
 /* |e|^2 of the last svcal_eval alone (two doubles come back instead of every block). */
 int svcal_sq_residual(svcal_ctx *ctx, double *out);
 

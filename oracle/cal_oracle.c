@@ -184,6 +184,52 @@ void orc_stereo_jacobian_dense(const double *vec, int k, int V, int C, const dou
     free(up); free(lo); free(U.extL); free(U.extR); free(L.extL); free(L.extR);
 }
 
+/* jacobian with update_intrinsics = false (CStereoCameraCalibration.cpp:187-245): only the
+ * 6 V + 6 columns of the views' left extrinsics and of the stereo pose, perturbed at
+ * offset 8 + 2 k of the parameter vector (:199-200).  Dense rows x (6 V + 6), row-major.
+ * A view's columns fill that view's LEFT rows (:207-224), the pose's columns all RIGHT
+ * rows (:226-240). */
+void orc_stereo_jacobian_dense_fixed_intrinsics(const double *vec, int k, int V, int C,
+                                                const double *world_xy, double *J)
+{
+    const double eps = 1.0e-6;
+    const int nI = 4 + k, all = 2 * nI + 6 * V + 6, cols = 6 * V + 6, offset = 2 * nI;
+    const size_t rows = (size_t)V * C * 4;
+    memset(J, 0, sizeof(double) * rows * cols);
+    double *up = (double *)malloc(sizeof(double) * all), *lo = (double *)malloc(sizeof(double) * all);
+    stereo_paras U, L;
+    U.extL = (double *)malloc(sizeof(double) * 12 * (size_t)V);
+    U.extR = (double *)malloc(sizeof(double) * 12 * (size_t)V);
+    L.extL = (double *)malloc(sizeof(double) * 12 * (size_t)V);
+    L.extR = (double *)malloc(sizeof(double) * 12 * (size_t)V);
+    for (int c = 0; c < cols; ++c) {
+        memcpy(up, vec, sizeof(double) * all);
+        memcpy(lo, vec, sizeof(double) * all);
+        up[c + offset] += eps; lo[c + offset] -= eps;
+        stereo_decompose(up, k, V, &U);
+        stereo_decompose(lo, k, V, &L);
+        for (int i = 0; i < V; ++i) {
+            if (c < cols - 6 && c / 6 != i) continue;                           /* :210 */
+            for (int j = 0; j < C; ++j) {
+                double a[2], b[2];
+                size_t row;
+                if (c < cols - 6) {
+                    orc_cal_value(U.intrL, U.distL, k, U.extL + 12 * i, world_xy[2 * j], world_xy[2 * j + 1], a);
+                    orc_cal_value(L.intrL, L.distL, k, L.extL + 12 * i, world_xy[2 * j], world_xy[2 * j + 1], b);
+                    row = 2 * ((size_t)i * C + j);
+                } else {
+                    orc_cal_value(U.intrR, U.distR, k, U.extR + 12 * i, world_xy[2 * j], world_xy[2 * j + 1], a);
+                    orc_cal_value(L.intrR, L.distR, k, L.extR + 12 * i, world_xy[2 * j], world_xy[2 * j + 1], b);
+                    row = 2 * ((size_t)V * C) + 2 * ((size_t)i * C + j);
+                }
+                J[row * cols + c] = (a[0] - b[0]) / (2.0 * eps);
+                J[(row + 1) * cols + c] = (a[1] - b[1]) / (2.0 * eps);
+            }
+        }
+    }
+    free(up); free(lo); free(U.extL); free(U.extR); free(L.extL); free(L.extR);
+}
+
 /* Block-sparse J^T J and J^T e of the same Jacobian and residual, without the
  * dense matrix.  nI = 4 + k.  Outputs (row-major, all symmetric blocks full):
  *   LL nI x nI, RR nI x nI, RS nI x 6, SS 6 x 6, LE V x nI x 6, EE V x 6 x 6,

@@ -170,6 +170,7 @@ def _cal_lib():
         L.orc_cal_value.argtypes = [dp, dp, C.c_int, dp, C.c_double, C.c_double, dp]
         L.orc_stereo_residual.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp]
         L.orc_stereo_jacobian_dense.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, dp]
+        L.orc_stereo_jacobian_dense_fixed_intrinsics.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, dp]
         L.orc_stereo_eval_sparse.restype = C.c_double
         L.orc_stereo_eval_sparse.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, dp, dp] + [dp] * 11
         L.orc_mono_residual_jacobian_dense.argtypes = [dp, C.c_int, C.c_int, dp, dp, dp, dp]
@@ -196,11 +197,17 @@ def stereo_residual(vec, k, world, left, right):
     return res
 
 
-def stereo_jacobian_dense(vec, k, world, V):
+def stereo_jacobian_dense(vec, k, world, V, update_intrinsics=True):
+    """The reference's dense Jacobian: every column (update_intrinsics, :95-186) or the
+    6 V + 6 columns of the views and the pose only (:187-245)."""
     vec, world = _dd(vec), _dd(world)
     Cn = world.shape[0]
-    J = np.empty((4 * V * Cn, len(vec)))
-    _cal_lib().orc_stereo_jacobian_dense(_d(vec), k, V, Cn, _d(world), _d(J))
+    if update_intrinsics:
+        J = np.empty((4 * V * Cn, len(vec)))
+        _cal_lib().orc_stereo_jacobian_dense(_d(vec), k, V, Cn, _d(world), _d(J))
+    else:
+        J = np.empty((4 * V * Cn, 6 * V + 6))
+        _cal_lib().orc_stereo_jacobian_dense_fixed_intrinsics(_d(vec), k, V, Cn, _d(world), _d(J))
     return J
 
 

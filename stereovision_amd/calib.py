@@ -36,6 +36,7 @@ CAL_SYMBOLS = {
     "svcal_eval": (C.c_int, [C.c_void_p]),
     "svcal_fetch": (C.c_int, [C.c_void_p, C.POINTER(_Blocks)]),
     "svcal_sq_residual": (C.c_int, [C.c_void_p, _dp]),
+    "svcal_set_update_intrinsics": (C.c_int, [C.c_void_p, C.c_int]),
     "svcal_solve_damped": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp]),
     "svcal_solve_begin": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
     "svcal_solve_end": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, _dp, _dp]),
@@ -137,6 +138,11 @@ class ReprojectionEvaluator:
         self._check(self._lib.svcal_sq_residual(self._h, C.byref(out)))
         return out.value
 
+    def set_update_intrinsics(self, update_intrinsics):
+        """doStereoCalibrate's update_intrinsics: False freezes the 2 (4 + k) intrinsic and
+        distortion parameters in the device step (CStereoCameraCalibration.cpp:187-245)."""
+        self._check(self._lib.svcal_set_update_intrinsics(self._h, 1 if update_intrinsics else 0))
+
     def solve_damped(self, lam):
         """Device counterpart of solve_damped() below for the blocks of the last eval():
         (step in the reference's parameter order, step^T (lam step - G))."""
@@ -212,13 +218,27 @@ def assemble_dense(blocks, k, V, stereo=True):
     return A, G
 
 
-def solve_damped(blocks, k, V, lam, stereo=True):
+def solve_damped(blocks, k, V, lam, stereo=True, update_intrinsics=True):
     """step = -(A + lam diag(A))^-1 G without forming A: the per-view 6 x 6 blocks are
     eliminated first (Schur complement), which leaves a system in the 2 (4 + k) + 6 shared
     parameters (4 + k monocular).  Equal to the dense solve of the reference
     (CStereoCameraCalibration.cpp:288-291) up to rounding, at O(V) cost instead of O(V^3).
+    update_intrinsics=False (:187-245): A holds the views' and the pose's columns only, i.e.
+    the views' 6 x 6 blocks and the pose's 6 x 6 block, each solved alone; the intrinsic
+    entries of the step are zero.
     Returns (step in the reference's parameter order, step^T (lam step - G))."""
     nI = 4 + k
+    if not update_intrinsics:
+        damp = lambda M: M + lam * M * np.eye(6)
+        de = -np.linalg.solve(damp(blocks["EE"]), blocks["gE"][:, :, None])[:, :, 0]
+        parts, grads = [np.zeros(2 * nI if stereo else nI), de.ravel()], [blocks["gE"].ravel()]
+        if stereo:
+            ds = -np.linalg.solve(damp(blocks["SS"]), blocks["gS"])
+            parts.append(ds)
+            grads.append(blocks["gS"])
+        step, G = np.concatenate(parts), np.concatenate(grads)
+        free = step[(2 * nI if stereo else nI):]
+        return step, float(free @ (lam * free - G))
     nC = 2 * nI + 6 if stereo else nI
     Acc, gc = np.zeros((nC, nC)), np.zeros(nC)
     Acc[:nI, :nI] = blocks["LL"]
@@ -249,7 +269,8 @@ def solve_damped(blocks, k, V, lam, stereo=True):
     return step, float(step @ (lam * step - G))
 
 
-def lm_refine(evaluator, params, k=5, max_iter=100, verbose=False, dense=False, host_solve=False):
+def lm_refine(evaluator, params, k=5, max_iter=100, verbose=False, dense=False, host_solve=False,
+              update_intrinsics=True):
     """The reference's damped Gauss-Newton loop (CStereoCameraCalibration.cpp:278-335):
     lambda0 = 1e-3, A + lambda diag(A), gain-ratio update, stops on |step| < 1e-5,
     |e| < 1e-3 or 100 iterations.  One device evaluation per trial step.  The linear solve
@@ -259,14 +280,23 @@ def lm_refine(evaluator, params, k=5, max_iter=100, verbose=False, dense=False, 
     x = np.array(params, np.float64)
     V, stereo = evaluator.V, evaluator.stereo
     if not (host_solve or dense) and hasattr(evaluator, "solve_damped"):
-        return _lm_refine_device(evaluator, x, k, max_iter, verbose)
+        evaluator.set_update_intrinsics(update_intrinsics)
+        try:
+            return _lm_refine_device(evaluator, x, k, max_iter, verbose)
+        finally:
+            evaluator.set_update_intrinsics(True)
 
     def solve(b, lam):
         if dense:
             A, G = assemble_dense(b, k, V, stereo)
+            if not update_intrinsics:                       # the columns from offset 8 + 2 k on (:284-285)
+                off = (2 if stereo else 1) * (4 + k)
+                A, G = A[off:, off:], G[off:]
+                free = -np.linalg.solve(A + lam * np.diag(np.diag(A)), G)
+                return np.concatenate([np.zeros(off), free]), float(free @ (lam * free - G))
             step = -np.linalg.solve(A + lam * np.diag(np.diag(A)), G)
             return step, float(step @ (lam * step - G))
-        return solve_damped(b, k, V, lam, stereo)
+        return solve_damped(b, k, V, lam, stereo, update_intrinsics)
 
     b = evaluator.evaluate(x, k, want_residual=False)
     err2 = b["sq_residual"]

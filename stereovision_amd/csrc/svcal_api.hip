@@ -34,6 +34,7 @@ struct svcal_ctx {
     bool solve_begun = false;        // svcal_solve_begin ran for the blocks now on the device
     double begun_lam = 0.0;          // the damping svcal_solve_begin was given
     bool imported = false;           // gram_sum holds sums over ALL ranks' views (svcal_shard_import)
+    int freeze_intrinsics = 0;       // 1: update_intrinsics = false of doStereoCalibrate
 };
 
 namespace {
@@ -339,7 +340,7 @@ int solve_second_half(svcal_ctx *ctx, double lam, double *step_out, double predi
     const int V = ctx->V, nI = 4 + ctx->k, P = param_count(ctx, ctx->k);
     const int blocks = (V + 63) / 64;
     hipLaunchKernelGGL(cal_shared_solve_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->gram_sum,
-                       ctx->sv_csum, nI, ctx->stereo, lam, ctx->sv_dc, ctx->sv_flags);
+                       ctx->sv_csum, nI, ctx->stereo, ctx->freeze_intrinsics, lam, ctx->sv_dc, ctx->sv_flags);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cfail(ctx, SVICP_ERR_HIP, who, e);
     hipLaunchKernelGGL(cal_view_step_kernel, dim3(blocks), dim3(64), 0, ctx->stream, ctx->gram_view,
@@ -364,6 +365,13 @@ int solve_second_half(svcal_ctx *ctx, double lam, double *step_out, double predi
     return SVICP_OK;
 }
 }  // namespace
+
+int svcal_set_update_intrinsics(svcal_ctx *ctx, int update_intrinsics)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    ctx->freeze_intrinsics = update_intrinsics ? 0 : 1;
+    return SVICP_OK;
+}
 
 int svcal_solve_damped(svcal_ctx *ctx, double lam, double *step_out, double *predicted_out)
 {

@@ -415,8 +415,13 @@ __global__ __launch_bounds__(256) void cal_contrib_sum_kernel(const double *__re
 // step: dc[0 .. nC), followed by dc^T (lam dc - gc) in dc[kMaxShared].
 __global__ __launch_bounds__(256) void cal_shared_solve_kernel(
     const double *__restrict__ gram_sum, const double *__restrict__ csum_in, int nI,
-    int stereo, double lam, double *__restrict__ dc_out, int *__restrict__ flags)
+    int stereo, int freeze, double lam, double *__restrict__ dc_out, int *__restrict__ flags)
 {
+    // freeze: the intrinsics keep their values (update_intrinsics = false,
+    // CStereoCameraCalibration.cpp:187-245: the Jacobian holds the views' and the pose's columns
+    // only).  Their rows and columns become the identity with a zero gradient, so their
+    // step is exactly zero and the pose block is solved alone; nothing of the views couples
+    // with what is left.
     __shared__ double S[kMaxShared][kMaxShared + 1];           // last column: the gradient
     __shared__ double csum[kSolveSums];
     const int nc = nI + 1, nC = stereo ? 2 * nI + 6 : nI;
@@ -434,10 +439,16 @@ __global__ __launch_bounds__(256) void cal_shared_solve_kernel(
             const int rr = r - nI, cc = c - nI;                // right intrinsics, then the pose
             a = GR[tri_at(rr, cc)];                            // (RR, RS, SS sit where u has them)
         }
-        S[r][c] = r == c ? a + lam * (r < nI ? GL[tri_at(r, r)] : GR[tri_at(r - nI, r - nI)]) : a;
+        a = r == c ? a + lam * (r < nI ? GL[tri_at(r, r)] : GR[tri_at(r - nI, r - nI)]) : a;
+        const int frozen = stereo ? 2 * nI : nI;               // the intrinsic parameters come first
+        if (freeze && (r < frozen || c < frozen)) a = r == c ? 1.0 : 0.0;
+        S[r][c] = a;
     }
-    for (int r = t; r < nC; r += 256)
-        S[r][kMaxShared] = r < nI ? GL[tri_at(r, 15)] - csum[r * nc + nI] : GR[tri_at(r - nI, 15)];
+    for (int r = t; r < nC; r += 256) {
+        double g = r < nI ? GL[tri_at(r, 15)] - csum[r * nc + nI] : GR[tri_at(r - nI, 15)];
+        if (freeze && r < (stereo ? 2 * nI : nI)) g = 0.0;
+        S[r][kMaxShared] = g;
+    }
     __syncthreads();
     // ---- Cholesky, column by column, the rest of the matrix updated as each column is done
     // (every entry of the rest by its own thread, one barrier per column) and the gradient
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(256) void cal_shared_solve_kernel(
     // the gradient of the shared parameters as the caller knows it (before elimination)
     if (t < nC) {
         const double g = t < nI ? GL[tri_at(t, 15)] : GR[tri_at(t - nI, 15)];
-        const double d = -x[t];
+        const double d = (freeze && t < (stereo ? 2 * nI : nI)) ? 0.0 : -x[t];
         dc_out[t] = d;
         term[t] = d * (lam * d - g);
     }

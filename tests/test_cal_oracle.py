@@ -194,3 +194,31 @@ def test_rectify_maps_properties(po):
     # argument errors of :68-69
     assert not po.rectify_maps(0, 48, KL, dL, KR, dR, pl, pr)[0]
     assert not po.rectify_maps(8, 8, KL, dL[:3], KR, dR[:3], pl, pr)[0]
+
+
+def test_fixed_intrinsics_jacobian_is_the_tail_of_the_full_one(po):
+    """update_intrinsics = false (CStereoCameraCalibration.cpp:187-245): the restated Jacobian
+    equals the last 6 V + 6 columns of the full one, its normal equations are block diagonal
+    (a view's 6 x 6 block from the left rows, the pose's from the right rows), and the
+    block-wise step of calib.solve_damped equals the dense solve of those columns."""
+    from stereovision_amd.calib import solve_damped
+    V, k = 3, 5
+    w, l, r, truth, start = synth.make_stereo_views(views=V)
+    J_full = po.stereo_jacobian_dense(start, k, w, V)
+    J = po.stereo_jacobian_dense(start, k, w, V, update_intrinsics=False)
+    off = 2 * (4 + k)
+    assert J.shape == (4 * V * l.shape[1], 6 * V + 6)
+    assert np.array_equal(J, J_full[:, off:])
+    e = po.stereo_residual(start, k, w, l, r)
+    A, G = J.T @ J, J.T @ e
+    mask = np.zeros_like(A, bool)
+    for v in range(V + 1):
+        mask[6 * v:6 * v + 6, 6 * v:6 * v + 6] = True
+    assert np.abs(A[~mask]).max() == 0.0
+    lam = 1e-3
+    dense = -np.linalg.solve(A + lam * np.diag(np.diag(A)), G)
+    sp = po.stereo_eval_sparse(start, k, w, l, r)
+    step, pred = solve_damped(sp, k, V, lam, update_intrinsics=False)
+    assert np.all(step[:off] == 0.0)
+    assert np.abs(step[off:] - dense).max() <= 1e-9 * np.abs(dense).max()
+    assert pred == pytest.approx(float(dense @ (lam * dense - G)), rel=1e-9)

@@ -310,3 +310,41 @@ def test_rectify_maps_argument_errors():
         rectify_maps(10, 10, K, np.zeros(3), K, np.zeros(3), K, K)
     with pytest.raises(SvicpError):
         rectify_maps(10, 10, K, np.zeros(5), K, np.zeros(5), np.zeros((3, 3)), K)
+
+
+def test_fixed_intrinsics_step_and_refinement_on_reference_corners(po):
+    """update_intrinsics = false (CStereoCameraCalibration.cpp:187-245, :284-285, :306) on the
+    reference's own corner tables: the device step leaves the intrinsics alone and equals the
+    dense solve of the oracle's restated Jacobian; the loop then refines poses only."""
+    from stereovision_amd.calib import ReprojectionEvaluator, lm_refine, solve_damped
+    c = np.load(os.path.join(GOLD, "testdata_corners.npz"))
+    w, l, r = c["world_stereo"], c["left"], c["right"]
+    V, k, off = 4, 5, 18
+    x0 = stereo_start(w, l, r, (640, 480), 535.0)
+    ev = ReprojectionEvaluator(w, l, r)
+    ev.set_params(x0, k)
+    ev.eval()
+    full_step, _ = ev.solve_damped(1e-3)
+    ev.set_update_intrinsics(False)
+    step, pred = ev.solve_damped(1e-3)
+    assert np.all(step[:off] == 0.0) and np.abs(full_step[:off]).max() > 0
+    J = po.stereo_jacobian_dense(x0, k, w, V, update_intrinsics=False)
+    e = po.stereo_residual(x0, k, w, l, r)
+    A, G = J.T @ J, J.T @ e
+    dense = -np.linalg.solve(A + 1e-3 * np.diag(np.diag(A)), G)
+    assert np.abs(step[off:] - dense).max() <= 1e-5 * np.abs(dense).max()
+    assert pred == pytest.approx(float(dense @ (1e-3 * dense - G)), rel=1e-5)
+    host_step, host_pred = solve_damped(ev.fetch(False), k, V, 1e-3, update_intrinsics=False)
+    assert np.abs(step - host_step).max() <= 1e-9 * np.abs(host_step).max()
+    ev.set_update_intrinsics(True)
+    again, _ = ev.solve_damped(1e-3)
+    assert np.array_equal(again, full_step)
+    # the loop: same result on the device, block-sparse on the host and densely
+    x_dev, err_dev = lm_refine(ev, x0, k, max_iter=30, update_intrinsics=False)
+    x_host, err_host = lm_refine(ev, x0, k, max_iter=30, host_solve=True, update_intrinsics=False)
+    x_dense, err_dense = lm_refine(ev, x0, k, max_iter=30, dense=True, update_intrinsics=False)
+    assert np.array_equal(x_dev[:off], x0[:off]) and np.array_equal(x_host[:off], x0[:off])
+    assert err_dev == pytest.approx(err_host, rel=1e-6) and err_dev == pytest.approx(err_dense, rel=1e-6)
+    e0 = po.stereo_residual(x0, k, w, l, r)
+    assert err_dev < np.sqrt(e0 @ e0)
+    ev.close()
