@@ -311,6 +311,18 @@ void orc_set_constants(float dist_threshold, int normals_k)
     g_normals_k = normals_k;
 }
 
+/* Sensitivity studies only (tests/test_oracle.py): every solve's X is displaced by
+ * +-amplitude per component, signs drawn from `seed`, before R and T are formed from it.
+ * It stands for the last bits in which Eigen's inverse() (CPoint2PlaneICP.cpp:109) may
+ * differ from this file's elimination.  amplitude = 0 (the default) changes nothing. */
+static double g_solve_noise = 0.0;
+static uint64_t g_solve_noise_state = 0;
+void orc_set_solve_perturbation(double amplitude, uint64_t seed)
+{
+    g_solve_noise = amplitude;
+    g_solve_noise_state = seed;
+}
+
 /* 20-NN of each reference point including itself; raw second moments  */
 /* about the origin, each term fl32(fl32(pj*pi)/20) summed in fp64;    */
 /* eigenvector of the smallest eigenvalue stored as fp32.              */
@@ -464,6 +476,12 @@ static int single_run(const orc_kdtree *T, const float *ref, const float *normal
     } else {
         for (int i = 0; i < 6; ++i) X[i] = NAN;
     }
+
+    if (g_solve_noise != 0.0)
+        for (int i = 0; i < 6; ++i) {
+            g_solve_noise_state = g_solve_noise_state * 6364136223846793005ull + 1442695040888963407ull;
+            X[i] += (g_solve_noise_state >> 63) ? g_solve_noise : -g_solve_noise;
+        }
 
     if (info) {
         double cnt = 0, swr = 0, sw = 0;

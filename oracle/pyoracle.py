@@ -150,6 +150,13 @@ def set_constants(dist_threshold=5.0, normals_k=20):
     _NORMALS_K = int(normals_k)
 
 
+def set_solve_perturbation(amplitude=0.0, seed=0):
+    """Sensitivity studies: displaces every solve's X by +-amplitude per component (0: off)."""
+    L = lib()
+    L.orc_set_solve_perturbation.argtypes = [C.c_double, C.c_uint64]
+    L.orc_set_solve_perturbation(float(amplitude), int(seed))
+
+
 def parse_txt(text: bytes):
     n = lib().orc_parse_txt(text, len(text), None, 0)
     out = np.empty(n, np.float32)

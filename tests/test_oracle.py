@@ -244,3 +244,36 @@ def test_synthetic_pair_with_inlier_fraction(side):
         _, _, src0, _ = synth.make_pair(side)
         d0, _ = cKDTree(tgt).query(src0)
         assert (d0 * d0 <= 5.0).mean() < 0.40
+
+
+def test_unpinned_third_party_bits_cannot_move_the_transform(po, pair):
+    """The reference's FLANN and Eigen are not available, so the last bits of its estimated
+    normals (SelfAdjointEigenSolver, CPoint2PlaneICP.cpp:148) and of each solve
+    (MatrixXd::inverse, :109) are unknown.  This bounds what they could change: every normal
+    component moved by one fp32 ulp up or down (random signs, re-normalisation left out, as a
+    differently rounded eigenvector would be), and every solve's X displaced by 1e-12 per
+    component, move the 5- and the 30-iteration transform of the bundled pair by less than
+    1e-7 rad and 1e-7 x extent: a tenth of the tolerance this path is held to."""
+    ref, src, gold = pair
+    tree = po.KDTree(ref)
+    normals = gold["normals"]
+    extent = float(np.ptp(ref, axis=0).max())
+    rng = np.random.default_rng(20251111)
+    worst_rot, worst_tr, flips = 0.0, 0.0, 0
+    for iters in (5, 30):
+        base = po.icp_point2plane(tree, normals, src, iters)
+        for trial in range(3):
+            up = rng.integers(0, 2, normals.shape).astype(bool)
+            moved = np.where(up, np.nextafter(normals, np.float32(2.0)), np.nextafter(normals, np.float32(-2.0)))
+            assert np.abs(moved.view(np.int32) - normals.view(np.int32)).max() == 1
+            po.set_solve_perturbation(1e-12, seed=trial + 1)
+            try:
+                r = po.icp_point2plane(tree, moved.astype(np.float32), src, iters)
+            finally:
+                po.set_solve_perturbation(0.0)
+            worst_rot = max(worst_rot, refmath.rot_angle(r["trans"][:3, :3], base["trans"][:3, :3]))
+            worst_tr = max(worst_tr, float(np.abs(r["trans"][:3, 3] - base["trans"][:3, 3]).max()))
+            flips += int((r["idx"] != base["idx"]).sum())
+    print(f"worst rotation change {worst_rot:.2e} rad, translation {worst_tr:.2e} "
+          f"(extent {extent:.0f}); {flips} correspondences differ over all runs")
+    assert worst_rot < 1e-7 and worst_tr < 1e-7 * extent
