@@ -187,8 +187,8 @@ int svicp_synchronize(svicp_ctx *ctx);
 /* The whole sharded registration in one call, the collective included.  Every rank
  * (one process and one context per GPU) holds the whole target and its part of the
  * source and calls svicp_shard_run with the same iteration count.  Per iteration: one
- * launch of the iteration kernel, then one RCCL all-reduce (sum, 128 doubles: the
- * rank's change of the 32 sums in the four copies the kernel keeps) on the context's
+ * launch of the iteration kernel, then one RCCL all-reduce (sum, 128 64-bit integers: the
+ * rank's change of the 32 fixed-point sums in the four copies the kernel keeps) on the context's
  * stream, in place; the next launch solves from the summed numbers on every rank
  * alike, so nothing is broadcast.  With options.use_graph the loop is captured in one
  * HIP graph (collectives included) and replayed; a runtime that refuses to capture the
@@ -208,14 +208,25 @@ int svicp_shard_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info
  * the communicator (1 without one).  Either pointer may be NULL. */
 int svicp_shard_run_mode(const svicp_ctx *ctx, int *captured, int *world_size);
 
+/* The sums are kept in 64-bit fixed point (their totals then do not depend on the order in
+ * which tiles or ranks are added up), scaled by bounds that include the number of source
+ * points.  Ranks that exchange sums must scale alike: each rank tells its context the size
+ * of the WHOLE source, the same number on every rank, after svicp_set_source and before
+ * svicp_shard_begin.  svicp_shard_run needs no such call (it agrees on the number over its
+ * communicator).  Without it a context scales for its own part only, which is right for one
+ * rank. */
+int svicp_shard_set_total(svicp_ctx *ctx, int64_t total_points);
+
 /* Resets the accumulated transform and the iteration counter. */
 int svicp_shard_begin(svicp_ctx *ctx);
 
 /* Solves the system of the previous iteration (from the totals every rank
  * holds identically), transforms this rank's source shard by it, finds
  * correspondences, and copies this rank's change of the 32 sums in this
- * iteration to device memory `dev_partial32`.  At most 1024 iterations per
- * svicp_shard_begin. */
+ * iteration to device memory `dev_partial32`: 32 x 8 bytes, to be added over the
+ * ranks as 64-bit INTEGERS (they are fixed-point numbers; the argument keeps its
+ * double * type for the callers that hold the block as raw 8-byte words).  At most
+ * 1024 iterations per svicp_shard_begin. */
 int svicp_shard_accumulate(svicp_ctx *ctx, double *dev_partial32);
 
 /* Takes the change summed over all ranks (device memory); the next

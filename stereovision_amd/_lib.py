@@ -70,6 +70,7 @@ SYMBOLS = {
     "svicp_comm_destroy": (C.c_int, [_ctx]),
     "svicp_shard_run": (C.c_int, [_ctx, C.c_int, _dp, C.POINTER(Info)]),
     "svicp_shard_run_mode": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "svicp_shard_set_total": (C.c_int, [_ctx, C.c_int64]),
     "svicp_shard_begin": (C.c_int, [_ctx]),
     "svicp_shard_accumulate": (C.c_int, [_ctx, C.c_void_p]),
     "svicp_shard_update": (C.c_int, [_ctx, C.c_void_p]),

@@ -175,6 +175,11 @@ struct svicp_ctx {
 
     // iteration loop
     DevBuf partials, totals, deltas, state, xhist, ihist;
+    // fixed-point exponents of the 30 sums (see update_fixed_point) and what they are made from
+    DevBuf fx_exp;
+    int fx_host[kNumSums] = {};
+    float tgt_maxabs = 0.f, nrm_maxabs = 1.f;
+    int64_t total_points = 0;      // source points over ALL ranks of a sharded run (0: this context's own)
     IcpState *h_state = nullptr;   // pinned and mapped: the kernel that ends a run writes it
     IcpState *h_state_dev = nullptr;
     bool h_state_pinned = false;   // h_state came from hipHostMalloc (a batch member's is plain memory)
@@ -294,6 +299,44 @@ int device_bbox(svicp_ctx *ctx, const float *aos, int64_t n, float mn[3], float 
             mn[a] = std::min(mn[a], h[6 * b + a]);
             mx[a] = std::max(mx[a], h[6 * b + 3 + a]);
         }
+    return SVICP_OK;
+}
+
+// Exponents of the fixed-point sums (svicp_device.hpp, fx_t): sum t is kept as
+// round(value * 2^e_t) with e_t = 62 - ceil(log2(bound_t)), bound_t an upper bound of |sum t|:
+// points x (largest rotation-column entry)^nrot x (largest normal component)^ntr x
+// (largest residual)^nb, from the target's largest coordinate, the largest normal component and
+// the threshold (a point contributes only while it lies within sqrt(threshold) of a target
+// point).  Every rank of a sharded run must arrive at the same table: the point count is then
+// the one agreed over the ranks (ctx->total_points).  Uploaded here, at set-up time; the
+// run paths only read it.
+int update_fixed_point(svicp_ctx *ctx)
+{
+    const double thr = ctx->opt.dist_threshold, root = std::sqrt(thr);
+    const double smax = (double)ctx->tgt_maxabs + root + 1.0;
+    const double nmax = std::isfinite(ctx->nrm_maxabs) && ctx->nrm_maxabs > 0.f ? (double)ctx->nrm_maxabs : 1.0;
+    const double A = 2.0 * smax * nmax * 1.01, Nn = nmax * 1.01, B = 3.0 * root * nmax * 1.01;
+    const double npts = (double)std::max<int64_t>(ctx->total_points > 0 ? ctx->total_points : ctx->n, 1);
+    auto exponent = [&](int nrot, int ntr, int nb) {
+        double bound = npts * std::pow(A, nrot) * std::pow(Nn, ntr) * std::pow(B, nb);
+        if (!(bound >= 1.0)) bound = 1.0;
+        const int e = 62 - (int)std::ceil(std::log2(bound));
+        return std::max(-900, std::min(e, 62));
+    };
+    int t = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) {
+            const int nrot = (r < 3) + (c < 3);
+            ctx->fx_host[t++] = exponent(nrot, 2 - nrot, 0);
+        }
+    for (int r = 0; r < 6; ++r) ctx->fx_host[t++] = exponent(r < 3, r >= 3, 1);
+    ctx->fx_host[27] = exponent(0, 0, 0);
+    ctx->fx_host[28] = exponent(0, 0, 2);
+    ctx->fx_host[29] = exponent(0, 0, 0);
+    ctx->fx_host[30] = ctx->fx_host[31] = 0;
+    HIPCHK(ctx->fx_exp.reserve(sizeof(int) * kNumSums));
+    HIPCHK(hipMemcpyAsync(ctx->fx_exp.p, ctx->fx_host, sizeof(int) * kNumSums, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return SVICP_OK;
 }
 
@@ -432,7 +475,8 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
 // The small buffers of one iteration loop: the context's own, or (svicp_run_enqueue) places in
 // the device's file-scope workspace.
 struct LoopBufs {
-    double *partials, *totals, *deltas, *xhist, *ihist;
+    double *partials, *xhist, *ihist;
+    fx_t *totals, *deltas;
     IcpState *state;
     unsigned char *flags;    // [2][kFlagCap] or null
 };
@@ -441,8 +485,8 @@ LoopBufs own_bufs(svicp_ctx *ctx)
 {
     LoopBufs b;
     b.partials = ctx->partials.as<double>();
-    b.totals = ctx->totals.as<double>();
-    b.deltas = ctx->deltas.as<double>();
+    b.totals = ctx->totals.as<fx_t>();
+    b.deltas = ctx->deltas.as<fx_t>();
     b.xhist = ctx->xhist.as<double>();
     b.ihist = ctx->ihist.as<double>();
     b.state = ctx->state.as<IcpState>();
@@ -466,14 +510,15 @@ void launch_iteration(svicp_ctx *ctx, int k, const LoopBufs &b)
     float *wx = ctx->wx.as<float>(), *wy = ctx->wy.as<float>(), *wz = ctx->wz.as<float>();
     const float *x0 = ctx->sx0.as<float>(), *y0 = ctx->sy0.as<float>(), *z0 = ctx->sz0.as<float>();
     IcpState *state = b.state;
-    double *tot = b.totals, *del = b.deltas;
+    fx_t *tot = b.totals, *del = b.deltas;
+    const int *fx = ctx->fx_exp.as<int>();
     double *xh = b.xhist, *ih = b.ihist;
     double *partials = b.partials;
     const dim3 grid(ctx->nb), block(kItThreads);
     const int n = (int)ctx->n;
 #define SVICP_ITERATE(APPLY, CERTIFY, INPLACE, ix, iy, iz)                                        \
     hipLaunchKernelGGL((icp_iterate_kernel<APPLY, CERTIFY, 4, INPLACE>), grid, block, 0, ctx->stream, \
-                       tot, del, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, \
+                       tot, del, fx, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, \
                        xh, ih, cp, partials, ctx->g)
     // iteration 0 reads the source as set and moves nothing, iteration 1 reads it and writes
     // the moving copy, later ones update the moving copy where it is
@@ -503,8 +548,8 @@ int enqueue_loop(svicp_ctx *ctx, int iters, bool timed, const LoopBufs &b, IcpSt
     }
     // the last iteration's system is solved here; the others were solved at the
     // start of the following iteration's kernel
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, b.totals, b.deltas, b.state,
-                       b.xhist, b.ihist, iters - 1, host_copy, dev_out);
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, b.totals, b.deltas,
+                       ctx->fx_exp.as<int>(), b.state, b.xhist, b.ihist, iters - 1, host_copy, dev_out);
     LAUNCHCHK("solve_kernel");
     return SVICP_OK;
 }
@@ -578,13 +623,15 @@ int enqueue_shard_loop(svicp_ctx *ctx, int iters)
         launch_iteration(ctx, k, b);
         LAUNCHCHK("icp_iterate_kernel");
         if (ctx->comm) {
-            double *row = b.deltas + (size_t)k * kDeltaRow;
-            ncclResult_t r = api->AllReduce(row, row, kDeltaRow, ncclDouble, ncclSum, ctx->comm, ctx->stream);
+            // 64-bit integers: the sum over the ranks is exact, whatever order RCCL adds them in
+            fx_t *row = b.deltas + (size_t)k * kDeltaRow;
+            ncclResult_t r = api->AllReduce(row, row, kDeltaRow, ncclInt64, ncclSum, ctx->comm, ctx->stream);
             if (r != ncclSuccess) return fail_rccl(ctx, "ncclAllReduce", r);
         }
     }
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, b.totals, b.deltas, b.state,
-                       b.xhist, b.ihist, iters - 1, ctx->h_state_dev, (double *)nullptr);
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, b.totals, b.deltas,
+                       ctx->fx_exp.as<int>(), b.state, b.xhist, b.ihist, iters - 1, ctx->h_state_dev,
+                       (double *)nullptr);
     LAUNCHCHK("solve_kernel");
     return SVICP_OK;
 }
@@ -659,7 +706,7 @@ int svicp_destroy(svicp_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->quad, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx,
                        &ctx->wy, &ctx->wz, &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->tile_flags, &ctx->perm,
                        &ctx->partials, &ctx->totals, &ctx->deltas, &ctx->state, &ctx->xhist, &ctx->ihist,
-                       &ctx->p2p_sums, &ctx->rthist };
+                       &ctx->p2p_sums, &ctx->rthist, &ctx->fx_exp };
     for (DevBuf *b : bufs) b->release();          // (slices of an arena are the arena's to free)
     ctx->own_scr.release();
     if (ctx->h_state && ctx->h_state_pinned) (void)hipHostFree(ctx->h_state);
@@ -758,6 +805,7 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
     }
     float maxabs = 0.f;
     for (int a = 0; a < 3; ++a) maxabs = std::max(maxabs, std::max(std::fabs(mn[a]), std::fabs(mx[a])));
+    ctx->tgt_maxabs = maxabs;
     const float r = std::sqrt(ctx->opt.dist_threshold);
     const float eps_abs = maxabs * (1.0f / 1048576.0f);
     GridDesc g{};
@@ -883,10 +931,22 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
                            ctx->scr->tgt_aos.as<float>(), ctx->scr->nrm_aos.as<float>(), ctx->scr->vals_b.as<int>(),
                            (int)m, ctx->pts.as<float4>(), ctx->nrm.as<float>());
         LAUNCHCHK("gather_target_kernel(normals)");
+        // the largest normal component bounds the sums (estimated normals are unit vectors;
+        // given ones are taken as they come)
+        ctx->nrm_maxabs = 1.f;
+        if (normals_aos) {
+            float nmn[3], nmx[3];
+            int rc = device_bbox(ctx, ctx->scr->nrm_aos.as<float>(), m, nmn, nmx);
+            if (rc) return rc;
+            float nm = 0.f;
+            for (int a = 0; a < 3; ++a) nm = std::max(nm, std::max(std::fabs(nmn[a]), std::fabs(nmx[a])));
+            if (!std::isfinite(nm)) return fail(ctx, SVICP_ERR_ARG, "svicp_set_target: non-finite normals");
+            ctx->nrm_maxabs = std::max(nm, 1e-30f);
+        }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_target = true;
-    return SVICP_OK;
+    return update_fixed_point(ctx);
 }
 
 int svicp_get_normals(svicp_ctx *ctx, float *normals_aos_out)
@@ -969,7 +1029,8 @@ int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n)
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_source = true;
-    return SVICP_OK;
+    ctx->total_points = 0;          // a sharded run agrees on the total again
+    return update_fixed_point(ctx);
 }
 
 int svicp_get_source(svicp_ctx *ctx, float *xyz_aos_out)
@@ -1079,8 +1140,8 @@ int svicp_run_enqueue(svicp_ctx *ctx, int iterations, double *dev_out20)
     unsigned char *w = ctx->enq_scratch;    // the device address, never the array's name
     LoopBufs b;
     b.state = reinterpret_cast<IcpState *>(w + kEnqOffState);
-    b.totals = reinterpret_cast<double *>(w + kEnqOffTotals);
-    b.deltas = reinterpret_cast<double *>(w + kEnqOffDeltas);
+    b.totals = reinterpret_cast<fx_t *>(w + kEnqOffTotals);
+    b.deltas = reinterpret_cast<fx_t *>(w + kEnqOffDeltas);
     b.xhist = reinterpret_cast<double *>(w + kEnqOffXhist);
     b.ihist = reinterpret_cast<double *>(w + kEnqOffIhist);
     b.flags = nb <= kFlagCap ? w + kEnqOffFlags : nullptr;
@@ -1132,15 +1193,15 @@ int svicp_search_counts(svicp_ctx *ctx, int capacity_rows, double *counts_out)
     if (capacity_rows < ctx->last_iters)
         return fail(ctx, SVICP_ERR_ARG, "svicp_search_counts: capacity_rows is below the last run's iterations");
     HIPCHK(hipSetDevice(ctx->device));
-    std::vector<double> rows((size_t)kDeltaRow * ctx->last_iters);
-    HIPCHK(hipMemcpyAsync(rows.data(), ctx->deltas.p, sizeof(double) * rows.size(),
+    std::vector<fx_t> rows((size_t)kDeltaRow * ctx->last_iters);
+    HIPCHK(hipMemcpyAsync(rows.data(), ctx->deltas.p, sizeof(fx_t) * rows.size(),
                           hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     // row 0 was cleared for the next run; iteration 0 searches every point
     counts_out[0] = (double)ctx->n;
     for (int k = 1; k < ctx->last_iters; ++k) {
         double c = 0.0;
-        for (int cp = 0; cp < kDeltaCopies; ++cp) c += rows[(size_t)k * kDeltaRow + cp * kNumSums + 31];
+        for (int cp = 0; cp < kDeltaCopies; ++cp) c += (double)rows[(size_t)k * kDeltaRow + cp * kNumSums + 31];
         counts_out[k] = c;
     }
     return SVICP_OK;
@@ -1251,6 +1312,20 @@ int svicp_shard_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info
     HIPCHK(hipSetDevice(ctx->device));
     int rc = ensure_iteration_buffers(ctx, iterations);
     if (rc) return rc;
+    if (ctx->comm && ctx->comm_world > 1 && ctx->total_points == 0) {
+        // every rank must scale its sums alike: agree on the largest part of the source
+        // (once per source: a blocking exchange of one 64-bit integer)
+        long long *slot = reinterpret_cast<long long *>(ctx->fx_exp.as<int>() + 30);
+        long long mine = (long long)ctx->n, most = 0;
+        HIPCHK(hipMemcpyAsync(slot, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+        ncclResult_t r = rccl_api()->AllReduce(slot, slot, 1, ncclInt64, ncclMax, ctx->comm, ctx->stream);
+        if (r != ncclSuccess) return fail_rccl(ctx, "ncclAllReduce(max points)", r);
+        HIPCHK(hipMemcpyAsync(&most, slot, sizeof most, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->total_points = (int64_t)most * ctx->comm_world;
+        rc = update_fixed_point(ctx);
+        if (rc) return rc;
+    }
     const bool capture = ctx->opt.use_graph && ctx->stream != nullptr && !ctx->shard_capture_failed;
     bool launched = false;
     if (capture) {
@@ -1301,6 +1376,16 @@ int svicp_shard_run_mode(const svicp_ctx *ctx, int *captured, int *world_size)
     return SVICP_OK;
 }
 
+int svicp_shard_set_total(svicp_ctx *ctx, int64_t total_points)
+{
+    if (!ctx || total_points < 0) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_set_total: bad argument");
+    if (!ctx->have_target || !ctx->have_source)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_shard_set_total: set the target and the source first");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->total_points = std::max<int64_t>(total_points, ctx->n);
+    return update_fixed_point(ctx);
+}
+
 int svicp_shard_begin(svicp_ctx *ctx)
 {
     if (!ctx) return SVICP_ERR_ARG;
@@ -1330,7 +1415,7 @@ int svicp_shard_accumulate(svicp_ctx *ctx, double *dev_partial32)
     LAUNCHCHK("icp_iterate_kernel");
     // this rank's change of the sums in iteration k
     hipLaunchKernelGGL(fold_delta_kernel, dim3(1), dim3(64), 0, ctx->stream,
-                       ctx->deltas.as<double>() + (size_t)k * kDeltaRow, dev_partial32);
+                       ctx->deltas.as<fx_t>() + (size_t)k * kDeltaRow, reinterpret_cast<fx_t *>(dev_partial32));
     LAUNCHCHK("fold_delta_kernel");
     if (ctx->shard_iter >= 1) ctx->cur = 1;
     return SVICP_OK;
@@ -1342,8 +1427,9 @@ int svicp_shard_update(svicp_ctx *ctx, const double *dev_sum32)
     HIPCHK(hipSetDevice(ctx->device));
     // the summed change replaces this rank's own; the next svicp_shard_accumulate
     // (or _finish) adds it to the running totals and solves
-    hipLaunchKernelGGL(unfold_delta_kernel, dim3(1), dim3(256), 0, ctx->stream, dev_sum32,
-                       ctx->deltas.as<double>() + (size_t)ctx->shard_iter * kDeltaRow);
+    hipLaunchKernelGGL(unfold_delta_kernel, dim3(1), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const fx_t *>(dev_sum32),
+                       ctx->deltas.as<fx_t>() + (size_t)ctx->shard_iter * kDeltaRow);
     LAUNCHCHK("unfold_delta_kernel");
     ctx->shard_iter++;
     ctx->last_iters = ctx->shard_iter;
@@ -1355,8 +1441,8 @@ int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info)
     if (!ctx || !T_out) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_finish: NULL argument");
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->shard_iter < 1) return fail(ctx, SVICP_ERR_ARG, "svicp_shard_finish: no iteration was run");
-    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->totals.as<double>(),
-                       ctx->deltas.as<double>(), ctx->state.as<IcpState>(),
+    hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->totals.as<fx_t>(),
+                       ctx->deltas.as<fx_t>(), ctx->fx_exp.as<int>(), ctx->state.as<IcpState>(),
                        ctx->xhist.as<double>(), ctx->ihist.as<double>(), ctx->shard_iter - 1,
                        (IcpState *)nullptr, (double *)nullptr);
     LAUNCHCHK("solve_kernel");
@@ -1659,7 +1745,7 @@ int svicp_batch_create_from_arrays(int device_id, int count, const int64_t *tgt_
         DevBuf *persistent[] = { &c->pts, &c->nrm, &c->dir, &c->quad, &c->sx0, &c->sy0, &c->sz0, &c->wx, &c->wy,
                                  &c->wz, &c->st_tp, &c->st_nv, &c->st_lb, &c->tile_flags, &c->perm, &c->partials,
                                  &c->totals, &c->deltas, &c->state, &c->xhist, &c->ihist, &c->p2p_sums,
-                                 &c->rthist };
+                                 &c->rthist, &c->fx_exp };
         for (DevBuf *d : persistent) d->arena = &b->arena;
         c->h_state = &b->host_states[i];
         c->h_state_pinned = false;
@@ -1737,7 +1823,8 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
         P.x0 = c->sx0.as<float>(); P.y0 = c->sy0.as<float>(); P.z0 = c->sz0.as<float>();
         P.wx = c->wx.as<float>(); P.wy = c->wy.as<float>(); P.wz = c->wz.as<float>();
         P.n = (int)c->n; P.nb = c->nb;
-        P.totals = c->totals.as<double>(); P.deltas = c->deltas.as<double>();
+        P.totals = c->totals.as<fx_t>(); P.deltas = c->deltas.as<fx_t>();
+        P.fx = c->fx_exp.as<int>();
         P.st = c->state.as<IcpState>();
         P.X_hist = c->xhist.as<double>(); P.info_hist = c->ihist.as<double>();
         P.cp.thr = thr;

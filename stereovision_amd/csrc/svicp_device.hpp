@@ -551,23 +551,42 @@ __device__ __forceinline__ double lane_bcast(double v, int lane)
 // The loads behind the running totals, issued by request_sums() and consumed by
 // solve_and_update().  Vector loads return in issue order, so the wave that solves asks
 // for these before anything else it loads.
+//
+// The running totals and their per-iteration changes are kept in 64-bit FIXED POINT: sum t is
+// stored as round(value * 2^fx[t]).  Integer addition is associative, so the totals do not
+// depend on the order in which the tiles' atomic additions (or the ranks of a sharded run)
+// arrive: two runs on the same input give the same bits, and every rank of a sharded run
+// solves from the same bits.  fx[t] is chosen on the host from bounds of the sums (number of
+// points, largest coordinate, largest normal component, threshold) so that the total stays
+// below 2^62; the resolution is finer than a double's for every sum.
+typedef long long fx_t;
+
 struct SumsInFlight {
-    double base, delta[kDeltaCopies];
+    fx_t base, delta[kDeltaCopies];
+    int exponent;
 };
 
-__device__ __forceinline__ SumsInFlight request_sums(const double *base, const double *delta)
+__device__ __forceinline__ SumsInFlight request_sums(const fx_t *base, const fx_t *delta, const int *fx)
 {
     const int t = threadIdx.x & 63;
     SumsInFlight s;
-    s.base = 0.0;
+    s.base = 0;
+    s.exponent = 0;
 #pragma unroll
-    for (int cp = 0; cp < kDeltaCopies; ++cp) s.delta[cp] = 0.0;
+    for (int cp = 0; cp < kDeltaCopies; ++cp) s.delta[cp] = 0;
     if (t < 30) {
         s.base = base[t];
 #pragma unroll
         for (int cp = 0; cp < kDeltaCopies; ++cp) s.delta[cp] = delta[cp * kNumSums + t];
+        s.exponent = fx[t];
     }
     return s;
+}
+
+// value -> fixed point (round to nearest)
+__device__ __forceinline__ fx_t to_fixed(double v, int exponent)
+{
+    return __double2ll_rn(ldexp(v, exponent));
 }
 
 // Wave-parallel solve, called by ONE full wave (64 lanes) with the sums requested by
@@ -580,7 +599,7 @@ __device__ __forceinline__ SumsInFlight request_sums(const double *base, const d
 // the elimination.  Lanes >= 6 run the same instructions on values nobody reads.
 // Restates CPoint2PlaneICP.cpp:109 (X), :111-119 (R = Rz*Ry*Rx, T) and
 // :36-39 / :52-55 (Trans = [R T; 0 1] * Trans).
-__device__ inline void solve_and_update(const SumsInFlight &sums, double *totals,
+__device__ inline void solve_and_update(const SumsInFlight &sums, fx_t *totals,
                                         IcpState *st, double *X_hist, double *info_hist,
                                         int iter, bool record, double *out_rt,
                                         unsigned long long *trace_row = nullptr)
@@ -592,13 +611,14 @@ __device__ inline void solve_and_update(const SumsInFlight &sums, double *totals
     // before, plus what the tiles that changed since have added or taken away.
     // Upper triangle: element (r, c), r <= c, sits at r*6 - r(r-1)/2 + (c - r).
     double stat = 0.0;                      // lanes 0..29 carry sum t
+    fx_t fixed = 0;
     if (t < 30) {
-        double dsum = 0.0;
+        fixed = sums.base;
 #pragma unroll
-        for (int cp = 0; cp < kDeltaCopies; ++cp) dsum += sums.delta[cp];
-        stat = sums.base + dsum;
+        for (int cp = 0; cp < kDeltaCopies; ++cp) fixed += sums.delta[cp];
+        stat = ldexp((double)fixed, -sums.exponent);
     }
-    if (record && t < kNumSums) totals[t] = stat;
+    if (record && t < kNumSums) totals[t] = fixed;
     SVICP_SOLVE_STAMP(10);
     // lane r < 6 takes row r of the matrix and element r of the right-hand side
     const int rr6 = t < 6 ? t : 5;
@@ -848,8 +868,8 @@ __device__ __forceinline__ int choose_tile(const uint4 v, int nb, int b, bool &p
 template <bool APPLY, bool CERTIFY, int CH, bool INPLACE = false>
 __device__ __forceinline__ void iterate_tile(
     const GridDesc &g, const float *sx_in_, const float *sy_in_, const float *sz_in_,
-    float *sx_out, float *sy_out, float *sz_out, int n, double *__restrict__ totals,
-    double *__restrict__ deltas,
+    float *sx_out, float *sy_out, float *sz_out, int n, fx_t *__restrict__ totals,
+    fx_t *__restrict__ deltas, const int *__restrict__ fx,
     IcpState *st, double *X_hist, double *info_hist, int iter, const CohParams &cp,
     const PointState &ps, double *__restrict__ partials, const int fixed_tile, const int nb,
     const bool solve_now = true, const double *__restrict__ rt_given = nullptr)
@@ -873,7 +893,7 @@ __device__ __forceinline__ void iterate_tile(
     SumsInFlight sums;
     if (APPLY && wv == 0 && solve_now)
         sums = request_sums(totals + (size_t)(iter - 1) * kNumSums,
-                            deltas + (size_t)(iter - 1) * kDeltaRow);
+                            deltas + (size_t)(iter - 1) * kDeltaRow, fx);
     // ---- which tile: fixed_tile, or (fixed_tile < 0) block blockIdx.x's place in the
     // order that puts the tiles with work first (choose_tile) ----
     int tile = fixed_tile;
@@ -920,7 +940,7 @@ __device__ __forceinline__ void iterate_tile(
     // than the longest run; row 0 is cleared by the kernel that ends a run)
     if (tile == 0)
         for (int k = threadIdx.x; k < kDeltaRow; k += kItThreads)
-            deltas[(size_t)(iter + 1) * kDeltaRow + k] = 0.0;
+            deltas[(size_t)(iter + 1) * kDeltaRow + k] = 0;
 
     // ---- B: the first wave solves the previous iteration's system.  Meanwhile, in a tile
     // that is expected to have work (it had some in the iteration before), the other waves
@@ -1099,8 +1119,9 @@ __device__ __forceinline__ void iterate_tile(
     // slot 31 of the iteration's delta row counts the searched points (a statistic
     // for the caller; the solve reads slots 0..29 only)
     if (threadIdx.x == 0 && total > 0)
-        atomicAdd(deltas + (size_t)iter * kDeltaRow + (tile & (kDeltaCopies - 1)) * kNumSums + 31,
-                  (double)total);
+        atomicAdd(reinterpret_cast<unsigned long long *>(deltas) + (size_t)iter * kDeltaRow +
+                      (tile & (kDeltaCopies - 1)) * kNumSums + 31,
+                  (unsigned long long)total);
 
     SVICP_STAMP(5);
     // ---- G: search the queued points (CPoint2PlaneICP.cpp:65-67) ----
@@ -1163,14 +1184,19 @@ __device__ __forceinline__ void iterate_tile(
     // the tile's old sums are asked for here, late: nothing else has to stay in registers
     // for them, and the block sum covers their latency
     double old_row = 0.0;
+    int exponent = 0;
+    if (threadIdx.x < 30) exponent = fx[threadIdx.x];
     if (APPLY && threadIdx.x < 30) old_row = partials[(size_t)threadIdx.x * nb + tile];
     const double s = block_sum_30(acc, red);
     if (threadIdx.x < 30) {
         partials[(size_t)threadIdx.x * nb + tile] = s;
-        const double d = s - old_row;
-        if (d != 0.0)
-            atomicAdd(deltas + (size_t)iter * kDeltaRow + (tile & (kDeltaCopies - 1)) * kNumSums +
-                          threadIdx.x, d);
+        // both rows go to fixed point before they are subtracted: the totals are then the exact
+        // integer sum of the tiles' current rows, whatever the order of the additions
+        const fx_t d = to_fixed(s, exponent) - to_fixed(old_row, exponent);
+        if (d != 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(deltas) + (size_t)iter * kDeltaRow +
+                          (tile & (kDeltaCopies - 1)) * kNumSums + threadIdx.x,
+                      (unsigned long long)d);
     }
     SVICP_STAMP(7);
 }
@@ -1178,7 +1204,7 @@ __device__ __forceinline__ void iterate_tile(
 template <bool APPLY, bool CERTIFY, int CH, bool INPLACE>
 __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     // what the first loads of a launch need comes first
-    double *__restrict__ totals, double *__restrict__ deltas, int iter, int n,
+    fx_t *__restrict__ totals, fx_t *__restrict__ deltas, const int *__restrict__ fx, int iter, int n,
     unsigned char *ps_active, Float3 *ps_tp, Float3 *ps_nv, float *ps_lb,   // a PointState, member by member
     const float *sx_in, const float *sy_in, const float *sz_in, float *sx_out, float *sy_out,
     float *sz_out, IcpState *st, double *X_hist, double *info_hist, CohParams cp,
@@ -1189,7 +1215,7 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     ps.tp = ps_tp; ps.nv = ps_nv; ps.lb = ps_lb; ps.active = ps_active;
     const bool adaptive = APPLY && CERTIFY && ps.active != nullptr;
     iterate_tile<APPLY, CERTIFY, CH, INPLACE>(g, sx_in, sy_in, sz_in, sx_out, sy_out, sz_out, n,
-                                              totals, deltas, st, X_hist, info_hist, iter, cp, ps,
+                                              totals, deltas, fx, st, X_hist, info_hist, iter, cp, ps,
                                               partials,
                                               adaptive ? -1 : xcd_contiguous((int)blockIdx.x, nb), nb);
 }
@@ -1204,7 +1230,8 @@ struct BatchPair {
     const float *x0, *y0, *z0;   // the source as set
     float *wx, *wy, *wz;         // the moving copy
     int n, nb;
-    double *totals, *deltas;
+    fx_t *totals, *deltas;
+    const int *fx;
     IcpState *st;
     double *X_hist, *info_hist;
     CohParams cp;
@@ -1230,7 +1257,7 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_batch_kernel(
     // it and writes the moving copy, later ones update the moving copy in place
     const bool first = iter <= 1;
     iterate_tile<APPLY, CERTIFY, CH>(g, first ? P->x0 : wx, first ? P->y0 : wy, first ? P->z0 : wz,
-                                     wx, wy, wz, P->n, P->totals, P->deltas, P->st, P->X_hist,
+                                     wx, wy, wz, P->n, P->totals, P->deltas, P->fx, P->st, P->X_hist,
                                      P->info_hist, iter, cp, ps, P->partials, m.y, P->nb,
                                      /* solve_now = */ false, rt_all + 12 * (size_t)m.x);
 }
@@ -1245,9 +1272,9 @@ __global__ __launch_bounds__(64) void batch_reset_kernel(const BatchPair *__rest
     if (t < 9) st->R[t] = (t % 4 == 0) ? 1.0 : 0.0;
     if (t < 3) st->T[t] = 0.0;
     if (t < 16) st->Trans[t] = (t % 5 == 0) ? 1.0 : 0.0;
-    if (t < kNumSums) { st->S[t] = 0.0; P->totals[t] = 0.0; }
+    if (t < kNumSums) { st->S[t] = 0.0; P->totals[t] = 0; }
     if (t == 0) st->status = 0;
-    for (int k = t; k < iters * kDeltaRow; k += 64) P->deltas[k] = 0.0;
+    for (int k = t; k < iters * kDeltaRow; k += 64) P->deltas[k] = 0;
 }
 
 // One wave per pair: the solve of iteration `iter` (before the launch of iteration iter + 1,
@@ -1260,12 +1287,12 @@ __global__ __launch_bounds__(64) void batch_solve_kernel(const BatchPair *__rest
     __shared__ double rt[12];
     const BatchPair *P = pairs + blockIdx.x;
     solve_and_update(request_sums(P->totals + (size_t)iter * kNumSums,
-                                  P->deltas + (size_t)iter * kDeltaRow),
+                                  P->deltas + (size_t)iter * kDeltaRow, P->fx),
                      P->totals + (size_t)(iter + 1) * kNumSums, P->st, P->X_hist, P->info_hist, iter,
                      true, rt);
     __syncthreads();
     if (threadIdx.x < 12) rt_all[12 * (size_t)blockIdx.x + threadIdx.x] = rt[threadIdx.x];
-    for (int k = threadIdx.x; k < kDeltaRow; k += 64) P->deltas[k] = 0.0;   // clean for the pair's next run
+    for (int k = threadIdx.x; k < kDeltaRow; k += 64) P->deltas[k] = 0;   // clean for the pair's next run
 }
 
 // Gathers every pair's state into one array for a single copy to the host.
@@ -1284,20 +1311,20 @@ __global__ void batch_collect_kernel(const BatchPair *__restrict__ pairs, int co
 // dev_out (device memory, or null): the accumulated transform (16 doubles, row-major) and
 // {status, inliers, sum w b^2, |X|} of the last iteration, kRunOutDoubles doubles in all.
 constexpr int kRunOutDoubles = 20;
-__global__ __launch_bounds__(64) void solve_kernel(double *totals, double *deltas,
+__global__ __launch_bounds__(64) void solve_kernel(fx_t *totals, fx_t *deltas, const int *fx,
                                                    IcpState *st, double *X_hist,
                                                    double *info_hist, int iter, IcpState *host_copy,
                                                    double *dev_out)
 {
     __shared__ double rt[12];
     solve_and_update(request_sums(totals + (size_t)iter * kNumSums,
-                                  deltas + (size_t)iter * kDeltaRow),
+                                  deltas + (size_t)iter * kDeltaRow, fx),
                      totals + (size_t)(iter + 1) * kNumSums, st, X_hist, info_hist, iter, true,
                      rt);
     __syncthreads();
     // leave the first delta row clean for the next run, and hand the state to the
     // host through mapped memory (one store per lane instead of a copy command)
-    for (int k = threadIdx.x; k < kDeltaRow; k += 64) deltas[k] = 0.0;
+    for (int k = threadIdx.x; k < kDeltaRow; k += 64) deltas[k] = 0;
     if (host_copy || dev_out) __threadfence();
     if (host_copy) {
         constexpr int W = sizeof(IcpState) / sizeof(double);
@@ -1317,21 +1344,21 @@ __global__ __launch_bounds__(64) void solve_kernel(double *totals, double *delta
 }
 
 // Sharded runs: this rank's change of the sums in one iteration, copies added up.
-__global__ void fold_delta_kernel(const double *__restrict__ delta_row, double *__restrict__ out32)
+__global__ void fold_delta_kernel(const fx_t *__restrict__ delta_row, fx_t *__restrict__ out32)
 {
     const int t = threadIdx.x;
     if (t >= kNumSums) return;
-    double s = 0.0;
+    fx_t s = 0;
     for (int cp = 0; cp < kDeltaCopies; ++cp) s += delta_row[cp * kNumSums + t];
     out32[t] = s;
 }
 
 // Sharded runs: the change summed over all ranks replaces the rank's own (copy 0 holds
 // it, the other copies are cleared).
-__global__ void unfold_delta_kernel(const double *__restrict__ in32, double *__restrict__ delta_row)
+__global__ void unfold_delta_kernel(const fx_t *__restrict__ in32, fx_t *__restrict__ delta_row)
 {
     for (int k = threadIdx.x; k < kDeltaRow; k += blockDim.x)
-        delta_row[k] = k < kNumSums ? in32[k] : 0.0;
+        delta_row[k] = k < kNumSums ? in32[k] : 0;
 }
 
 __global__ void reset_state_kernel(IcpState *st)

@@ -228,6 +228,9 @@ class Context:
         self._check(self._lib.svicp_shard_run_mode(self._h, C.byref(a), C.byref(b)))
         return bool(a.value), b.value
 
+    def shard_set_total(self, total_points):
+        self._check(self._lib.svicp_shard_set_total(self._h, int(total_points)))
+
     def shard_begin(self):
         self._check(self._lib.svicp_shard_begin(self._h))
 

@@ -27,12 +27,26 @@ class HipShardEngine:
     def __init__(self, ctx, device):
         self.ctx = ctx
         self.device = torch.device(device)
-        self.buf = torch.zeros(32, dtype=torch.float64, device=self.device)
+        # the library's sums are 64-bit fixed-point numbers: integers as far as the exchange goes
+        self.buf = torch.zeros(32, dtype=torch.int64, device=self.device)
         # the library launches on torch's current stream, so collectives that
         # torch orders after that stream see finished sums
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def begin(self):
+    def begin(self, total_points=None, group=None):
+        """total_points: the size of the whole source (every rank must pass the same number);
+        None: asked of the process group (sum of the ranks' parts), or this rank's own part
+        when there is no group."""
+        if total_points is None:
+            n = self.ctx.sizes()[1]
+            if dist.is_initialized() and dist.get_world_size(group) > 1:
+                t = torch.tensor([n], dtype=torch.int64)
+                if dist.get_backend(group) == "nccl":
+                    t = t.to(self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                n = int(t.item())
+            total_points = n
+        self.ctx.shard_set_total(total_points)
         self.ctx.shard_begin()
 
     def accumulate(self):
@@ -40,7 +54,7 @@ class HipShardEngine:
         return self.buf
 
     def update(self, summed):
-        assert summed.is_cuda and summed.dtype == torch.float64 and summed.numel() == 32
+        assert summed.is_cuda and summed.dtype == torch.int64 and summed.numel() == 32
         self.ctx.shard_update(summed.data_ptr())
 
     def finish(self):
@@ -66,7 +80,7 @@ def run_sharded(engine, iterations, group=None):
     """The iteration loop of CPoint2PlaneICP::run (CPoint2PlaneICP.cpp:31-57)
     over a sharded source.  Returns what engine.finish() returns on this rank:
     the accumulated 4x4 transform (identical on every rank) and run info."""
-    engine.begin()
+    engine.begin(group=group) if isinstance(engine, HipShardEngine) else engine.begin()
     for _ in range(int(iterations)):
         buf = engine.accumulate()
         buf = all_reduce_sums(buf, group)

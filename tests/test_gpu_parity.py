@@ -676,3 +676,25 @@ def test_config4_slice_512_pairs_of_65536_points(po):
         r = po.icp_point2plane(po.KDTree(tg[i]), nr[i], sr[i], iters, threads=po.max_threads(), history=False)
         assert np.abs(Ts[i] - r["trans"]).max() < 1e-8
     batch.close()
+
+
+def test_two_runs_give_the_same_bits():
+    """The sums are kept in 64-bit fixed point, so the order in which the tiles' atomic
+    additions arrive cannot change them: two runs on the 1 M-point pair return bit-identical
+    solution vectors, transforms and moved sources, and so does a second context."""
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+    tgt, nrm, src, _ = synth.make_pair(1024)
+    outs = []
+    for _ in range(2):
+        with sv.Context(0) as c:
+            c.set_target(tgt, nrm)
+            c.set_source(src)
+            for rep in range(2):
+                T, info = c.run(30)
+                outs.append((T.copy(), c.history()[0].copy(), c.get_source().copy(), info.inliers))
+    for T, X, moved, inl in outs[1:]:
+        assert np.array_equal(T, outs[0][0])
+        assert np.array_equal(X, outs[0][1])
+        assert np.array_equal(moved, outs[0][2])
+        assert inl == outs[0][3]

@@ -32,9 +32,9 @@ def test_two_shards_in_one_process_match_unsharded(po):
         c.set_source(np.ascontiguousarray(src[b:e]))
         engines.append(HipShardEngine(c, "cuda:0"))
     for eng in engines:
-        eng.begin()
+        eng.begin(total_points=len(src))
     for _ in range(5):
-        total = torch.zeros(32, dtype=torch.float64, device="cuda:0")
+        total = torch.zeros(32, dtype=torch.int64, device="cuda:0")
         for eng in engines:
             total += eng.accumulate()
         for eng in engines:
