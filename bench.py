@@ -3,10 +3,13 @@
 
 A step is one registration of a synthetic 1024^2-point pair with analytic
 normals, 30 iterations, clouds resident in HBM (BASELINE.json configs[1]).
-With N > 1 ranks every rank registers its own independent pair (batch mode,
-no data-path collective) and `value` is the aggregate iterations/s; the same
-run also times the sharded mode (one 4096^2-point pair split over the ranks,
-one 32-double all-reduce per iteration) and reports it under "sharded".
+With N > 1 ranks every rank registers its own independent pair (no data-path
+collective) and `value` is the aggregate iterations/s.  The same run also
+times, at every N through the same code path:
+  * `value_sharded`: one 4096^2-point pair split over the ranks, the loop inside
+    the library (svicp_shard_run: iteration kernel + RCCL all-reduce per
+    iteration, captured in one HIP graph) - strong scaling;
+  * `batched`: 512 independent 65536-point pairs per rank in one arena batch.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -23,13 +26,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak
+FP64_VECTOR_PEAK_TF = 78.6  # half the 157.3 TF fp32 vector peak: CDNA4 issues fp64 FMAs at half rate
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--side", type=int, default=1024, help="points per cloud = side^2")
     ap.add_argument("--iters", type=int, default=30)
@@ -37,29 +41,52 @@ def parse():
                     help="side of the pair of the sharded leg; 0 disables the leg")
     ap.add_argument("--cpu-iters", type=int, default=30,
                     help="iterations of the CPU baseline sample; 0 disables it")
-    ap.add_argument("--batch-pairs", type=int, default=64,
+    ap.add_argument("--batch-pairs", type=int, default=512,
                     help="pairs (256^2 points each) per rank of the batched leg; 0 disables it")
     ap.add_argument("--extras", type=int, default=1,
-                    help="1: also time normal estimation, point-to-point ICP and rectification maps")
+                    help="1: also time normal estimation, point-to-point ICP, rectification maps "
+                         "and the drop-in call")
     ap.add_argument("--cal-views", type=int, default=2000,
                     help="views of the calibration leg (11 x 8 board each); 0 disables the leg")
     return ap.parse_args()
 
 
+def profile_figure(name):
+    """A figure kept under profiles/ by the counter passes of this same command (rocprofv3
+    --pmc cannot run inside the timed process); None when the file or the key is missing."""
+    for f in ("r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(ROOT, "profiles", f)
+        if os.path.exists(path):
+            with open(path) as fh:
+                d = json.load(fh)
+            if name in d:
+                return d[name], "profiles/" + f
+    return None, None
+
+
 def main():
     args = parse()
+    # Libraries underneath (RCCL prints a version banner when a communicator is made) write to
+    # the process's stdout; the one JSON line must be alone there.  Everything else goes to
+    # stderr: descriptor 1 points at stderr while the benchmark runs, and the line is written
+    # to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import stereovision_amd as sv
     from stereovision_amd import synth
-    from stereovision_amd.sharded import HipShardEngine, run_sharded, shard_bounds
+    from stereovision_amd.batched import HipBatchEngine, pair_bounds, run_pairs_split
+    from stereovision_amd.sharded import HipShardEngine, init_comm, run_sharded, run_sharded_native, shard_bounds
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     # SVICP_BENCH_BACKEND=gloo rehearses the multi-rank paths where the ranks outnumber the
-    # GPUs (ranks then share devices and the exchanges go through the host); the default is
+    # GPUs (ranks then share devices, the exchanges go through the host and the sharded leg
+    # falls back to the stepping calls: RCCL refuses two ranks on one device); the default is
     # RCCL, one rank per GPU
     backend = os.environ.get("SVICP_BENCH_BACKEND", "nccl")
     if backend != "nccl":
@@ -122,14 +149,14 @@ def main():
     launch_region_ms = region_ms / (args.steps * args.iters)
     elapsed = max_over_ranks(elapsed)
     value = world * args.steps * args.iters / elapsed
+    searched = ctx.search_counts()                    # points searched per iteration of a step
 
-    # ---- per-kernel durations: the same steps, eager, HIP events on the
-    # library's stream around every launch -------------------------------
-    # (the second value kernel_times returns is an event pair with nothing between
-    # its two records: what the pair itself adds to every measured launch)
+    # ---- per-launch durations: the same steps, eager, HIP events on the library's stream
+    # around every launch (kernel_times' second value is an event pair with nothing between
+    # its records: what the pair itself adds to every measured launch) ----
     ctx.set_options(time_kernels=1)
     fused, empty, per_iter = [], [], []
-    for _ in range(max(2, min(args.steps, 5))):
+    for _ in range(max(3, min(args.steps, 8))):
         ctx.run(args.iters)
         f, s, _ = ctx.kernel_times()
         fused.append(f)
@@ -142,28 +169,46 @@ def main():
     # algorithmic bytes of one launch of the iteration kernel: source read + write
     # (24 B/pt), target xyz + index + normal (28 B/pt), each touched once
     bytes_fused = 24.0 * n + 28.0 * len(tgt)
-    # the roofline figure uses the average over the timed region (events on the launch
-    # stream around all K x iters launches: gaps between launches and the one small solve
-    # launch that ends a step included); the per-launch event figures are kept beside it
-    achieved = bytes_fused / (launch_region_ms * 1e-3) / 1e9
-    slowest_ms = float(per_iter.max())            # a launch that searches every point
+    # the launches fall in two regimes: those that search (nearly) every point, which do the
+    # per-point work the byte model counts, and the settled ones, which skip the tiles whose
+    # points no longer move and are bound by latency, not by bytes
+    full = searched >= 0.9 * n
+    settled = np.zeros(args.iters, bool)
+    settled[8:] = searched[8:] < 0.001 * n
+    full_ms = float(per_iter[full].mean()) if full.any() else float("nan")
+    settled_ms = float(per_iter[settled].mean()) if settled.any() else float("nan")
+    achieved_full = bytes_fused / (full_ms * 1e-3) / 1e9
+    achieved_blend = bytes_fused / (launch_region_ms * 1e-3) / 1e9
+    traffic_full, traffic_src = profile_figure("icp_iterate_full_search_bytes_per_launch")
+    traffic_settled, _ = profile_figure("icp_iterate_settled_bytes_per_launch")
+    traffic_blend, traffic_blend_src = profile_figure("icp_iterate_kernel_bytes_per_launch")
+
     nn_capped_ms = ctx.time_nn(exact=False, reps=20)
     nn_exact_ms = ctx.time_nn(exact=True, reps=20)
+    loads_ms, loads_instr = ctx.time_gather(True, 0, 20)
+    hashed_ms, hashed_instr = ctx.time_gather(False, 16, 5)
     bytes_nn = 20.0 * n + 16.0 * len(tgt)
     # without the shortcut for points whose correspondence provably did not change
     ctx.set_options(coherent=0)
     ctx.run(args.iters)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    for _ in range(max(2, args.steps // 4)):
+        ctx.run(args.iters)
+    full_search_value = max(2, args.steps // 4) * args.iters / (time.perf_counter() - t0)
+    ctx.set_options(coherent=1)
+
+    # the same pair from the pose that leaves 70 % of the source within the threshold
+    _, _, src70, _ = synth.make_pair(args.side, pair=rank, inlier_frac=0.7)
+    ctx.set_source(src70)
+    ctx.run(args.iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(max(2, args.steps // 2)):
         ctx.run(args.iters)
-    full_search_value = max(2, args.steps // 2) * args.iters / (time.perf_counter() - t0)
-    ctx.set_options(coherent=1)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as fh:
-            traffic = json.load(fh).get("icp_iterate_kernel_bytes_per_launch")
+    value_inlier_pose = max(2, args.steps // 2) * args.iters / (time.perf_counter() - t0)
+    ctx.set_source(src)
+    ctx.run(args.iters)
 
     # ---- what this GPU's HBM delivers on a plain copy, for scale (torch is plumbing here:
     # one large device-to-device copy, read + write counted) ----
@@ -179,75 +224,88 @@ def main():
     stream_copy_gbs = 10 * 2.0 * a.numel() / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
     del a, b
 
-    # ---- sharded leg ----------------------------------------------------
+    # ---- sharded leg: one large pair, source split over the ranks, the loop inside the
+    # library at every N (N = 1 included: a one-rank communicator, the same graph) ----
     sharded = None
+    value_sharded = None
     if args.sharded_side > 0:
-        st, sn, ss, _ = synth.make_pair(args.sharded_side, pair=0)
-        b, e = shard_bounds(len(ss), world, rank)
+        st, sn, ss, spose = synth.make_pair(args.sharded_side, pair=0, inlier_frac=0.7)
+        b0, e0 = shard_bounds(len(ss), world, rank)
         sctx = sv.Context(local)
         sctx.set_target(st, sn)
-        sctx.set_source(np.ascontiguousarray(ss[b:e]))
+        sctx.set_source(np.ascontiguousarray(ss[b0:e0]))
+        n_sh = len(ss)
         del ss
-        if distributed:
-            eng = HipShardEngine(sctx, f"cuda:{local}")
-            run_sharded(eng, args.iters)
-            barrier()
-            t0 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                Ts, _ = run_sharded(eng, args.iters)
-            barrier()
-            dt = time.perf_counter() - t0
-            dt = max_over_ranks(dt)
+        native = backend == "nccl"
+        if native:
+            init_comm(sctx)
+            run_once = lambda: run_sharded_native(sctx, args.iters)
         else:
-            sctx.run(args.iters)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                Ts, _ = sctx.run(args.iters)
-            dt = time.perf_counter() - t0
-        sharded = {
-            "workload": f"one {args.sharded_side}^2-point pair, source split over {world} rank(s), "
-                        "target replicated, 32-double all-reduce per iteration",
-            "iters_per_s": reps * args.iters / dt,
-            "scaling": "strong",
-        }
-        sctx.close()
-
-    # ---- batched leg: many small independent pairs per rank, one launch per
-    # iteration for all of them; ranks take disjoint pairs, no collective ----
-    batched = None
-    if args.batch_pairs > 0:
-        bctx = []
-        for i in range(args.batch_pairs):
-            pid = rank * args.batch_pairs + i
-            bt, bn, bs, _ = synth.make_pair(256, pair=pid, pose=synth.small_pose(pid))
-            c = sv.Context(local)
-            c.set_target(bt, bn)
-            c.set_source(bs)
-            bctx.append(c)
-        batch = sv.Batch(bctx)
-        batch.run(args.iters)
+            eng = HipShardEngine(sctx, f"cuda:{local}")
+            run_once = lambda: run_sharded(eng, args.iters)
+        Ts, sinfo = run_once()
         barrier()
         t0 = time.perf_counter()
-        reps = 20
+        reps = 3
         for _ in range(reps):
-            batch.run(args.iters)
+            Ts, sinfo = run_once()
         barrier()
-        dt = time.perf_counter() - t0
-        dt = max_over_ranks(dt)
+        dt = max_over_ranks(time.perf_counter() - t0)
+        value_sharded = reps * args.iters / dt
+        captured, comm_world = sctx.shard_run_mode() if native else (False, world)
+        sharded = {
+            "workload": f"configs[2]: one {args.sharded_side}^2-point pair (start pose with 70 % of the "
+                        f"source within the threshold), source split over {world} rank(s), target "
+                        "replicated, one all-reduce of 128 64-bit fixed-point sums per iteration",
+            "iters_per_s": value_sharded, "scaling": "strong", "points": n_sh,
+            "path": "svicp_shard_run (iteration kernel + ncclAllReduce per iteration on one stream)"
+                    if native else "stepping calls + torch.distributed (rehearsal backend)",
+            "graph_captured": bool(captured), "communicator_world": comm_world,
+            "pose_error": float(np.abs(Ts @ spose - np.eye(4)).max()),
+            "measured_on": "this run's GPUs; N > 1 has not been measured on hardware by the builder",
+        }
+        if native:
+            sctx.comm_destroy()
+        sctx.close()
+
+    # ---- batched leg: configs[3]'s per-GPU slice, 512 independent 65536-point pairs per
+    # rank in one arena batch (one launch per iteration for all); ranks take disjoint pairs,
+    # no collective while iterating, one gather of the transforms at the end ----
+    batched = None
+    if args.batch_pairs > 0:
+        total_pairs = args.batch_pairs * world
+        first, last = pair_bounds(total_pairs, world, rank)
+        tg, nr, sr = [], [], []
+        for pid in range(first, last):
+            bt, bn, bs, _ = synth.make_pair(256, pair=pid, pose=synth.small_pose(pid))
+            tg.append(bt); nr.append(bn); sr.append(bs)
+        eng = HipBatchEngine(tg, nr, sr, device=local)
+        del tg, nr, sr
+        _, setup_ms, arena_bytes = eng.batch.info()
+        eng.run(args.iters)
+        barrier()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            eng.run(args.iters)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        Tall, _ = run_pairs_split(eng, total_pairs, args.iters)
+        gather_s = time.perf_counter() - t0
         batched = {
-            "workload": f"{args.batch_pairs} independent pairs of 65536 points per rank, "
-                        f"{args.iters} iterations, per-pair pose, one launch per iteration",
+            "workload": f"configs[3] slice: {args.batch_pairs} independent pairs of 65536 points per rank "
+                        f"({total_pairs} in all), {args.iters} iterations, per-pair pose, one launch per "
+                        "iteration for all pairs of a rank",
             "pair_iterations_per_s": world * reps * args.batch_pairs * args.iters / dt,
             "point_iterations_per_s": world * reps * args.batch_pairs * args.iters * 65536 / dt,
-            "device_ms_per_run": batch.last_ms(),
+            "device_ms_per_run": eng.batch.last_ms(),
+            "host_ms_per_run": dt / reps * 1e3,
+            "setup_ms": setup_ms, "arena_GiB": arena_bytes / 2 ** 30,
+            "run_and_gather_ms": gather_s * 1e3,
             "scaling": "weak",
         }
-        batch.close()
-        for c in bctx:
-            c.close()
+        eng.close()
 
     # ---- calibration leg: residual + Jacobian evaluations of the stereo refinement,
     # views split over the ranks, one 272-double all-reduce per evaluation ----
@@ -272,15 +330,34 @@ def main():
         else:
             eng.set_params(cstart, 5)
             eval_ms = eng.ev.time_eval(reps)      # HIP events around back-to-back evaluations
-        cal_bytes = 56.0 * V * cl.shape[1] + 48.0 * V
+        C = cl.shape[1]
+        cal_bytes = 56.0 * V * C + 48.0 * V
+        # fp64 operations per (view, corner, camera), five distortion terms, as the kernel is
+        # written: 13 geometric stages (12 multiply-adds of the 3 x 4 product, two divisions,
+        # r: 26 operations), 31 pixel stages (distortion polynomial, tangential terms,
+        # intrinsics: 36), 30 central differences (a subtraction and a division each), the
+        # residual, and two rank-1 updates of the 16 x 16 Gram matrix on the matrix cores
+        # (512 each); an operation is one add, multiply or divide
+        flops_unit = 13 * 26 + 31 * 36 + 30 * 2 + 2 + 2 * 512
+        flops_eval = flops_unit * 2.0 * V * C
+        tf = flops_eval / (eval_ms * 1e-3) / 1e12
         calibration = {
-            "workload": f"stereo reprojection residual + central-difference Jacobian reduced to "
-                        f"block-sparse normal equations, {V} views x {cl.shape[1]} corners "
-                        f"({4 * V * cl.shape[1]} residual rows, {18 + 6 * V + 6} parameters), "
+            "workload": f"configs[4]: stereo reprojection residual + central-difference Jacobian reduced to "
+                        f"block-sparse normal equations, {V} views x {C} corners "
+                        f"({4 * V * C} residual rows, {18 + 6 * V + 6} parameters), "
                         f"views split over {world} rank(s)",
             "evaluations_per_s": 1e3 / eval_ms, "ms_per_evaluation": eval_ms, "dtype": "f64",
             "algorithmic_GBs": cal_bytes / (eval_ms * 1e-3) / 1e9,
             "scaling": "strong",
+            "roofline": {
+                "bound": "fp64 vector", "kernel": "cal_eval_kernel<5> + cal_reduce_kernel",
+                "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TF,
+                "flops_per_view_corner_camera": flops_unit, "units": 2 * V * C,
+                "note": "56 of those operations per unit are IEEE divisions (about 20 issue slots each), "
+                        "so the issue-slot fraction is about twice the flop fraction; HBM is not the "
+                        "bound (algorithmic_GBs)",
+                "peak_source": "half the fp32 vector peak (157.3 TF) of MI355X_MICROARCH.md",
+            },
         }
         if not distributed:
             # the caller of the evaluation: one damped step of the refinement loop on the device
@@ -315,12 +392,14 @@ def main():
                 "kind": "port",
                 "sample": f"{nrep} block-sparse evaluations of the same {V}-view problem "
                           "(oracle/cal_oracle.c; the reference's dense Jacobian of "
-                          f"{4 * V * cl.shape[1]} x {18 + 6 * V + 6} doubles cannot be allocated)",
+                          f"{4 * V * C} x {18 + 6 * V + 6} doubles cannot be allocated)",
             }
 
     # ---- the rows next to the hot path, rank 0 only, small and bounded: normal estimation,
-    # the point-to-point variant, the rectification maps; each with the CPU checker beside it
+    # the point-to-point variant, the rectification maps, the drop-in call from host buffers;
+    # each with the CPU checker beside it
     neighbours = None
+    dropin = None
     if rank == 0 and args.extras:
         neighbours = {}
         ectx = sv.Context(local)
@@ -337,6 +416,27 @@ def main():
                         "build included (the CPU figure includes its tree build)",
             "ms": t_est * 1e3, "set_target_with_given_normals_ms": t_given * 1e3,
             "note": "the second call uploads 12 B of normals per point instead of estimating them"}
+        # the drop-in call as CPoint2PlaneICP::run of the compat classes makes it
+        # (CPoint2PlaneICP.cpp:31-62): host buffer in, 30 iterations, moved cloud back out
+        from stereovision_amd.icp import pinned_empty
+
+        def call(buf_in, buf_out):
+            t0 = time.perf_counter()
+            ectx.set_source(buf_in)
+            ectx.run(args.iters)
+            ectx.get_source(buf_out)
+            return (time.perf_counter() - t0) * 1e3
+        out_pageable = np.empty_like(src)
+        pin_in, pin_out = pinned_empty(src.shape), pinned_empty(src.shape)
+        pin_in[:] = src
+        call(src, out_pageable); call(pin_in, pin_out)
+        dropin = {
+            "workload": f"set_source + {args.iters} iterations + get_source, {n} points, host buffers "
+                        "(PCIe inclusive; never `value`)",
+            "dropin_call_ms": float(np.mean([call(src, out_pageable) for _ in range(5)])),
+            "dropin_call_ms_pinned_buffers": float(np.mean([call(pin_in, pin_out) for _ in range(5)])),
+            "note": "pinned: the clouds live in svicp_host_alloc memory, as the drop-in CTxtReader allocates them",
+        }
         ectx.close()
         pctx = sv.Context(local, dist_threshold=15.0)
         pctx.set_target(tgt, tgt)
@@ -356,8 +456,8 @@ def main():
         KR = np.array([[1395.0, 0, 955.0], [0, 1398.0, 545.0], [0, 0, 1]])
         dL = np.array([-0.28, 0.09, 1e-3, -5e-4, 0.01])
         dR = np.array([-0.27, 0.08, -7e-4, 4e-4, -0.02])
-        cr, sr = np.cos(0.01), np.sin(0.01)
-        Rrig = np.array([[cr, 0, sr], [0, 1, 0], [-sr, 0, cr]])
+        cr_, sr_ = np.cos(0.01), np.sin(0.01)
+        Rrig = np.array([[cr_, 0, sr_], [0, 1, 0], [-sr_, 0, cr_]])
         pl, pr, _ = stereo_rectify(KL, KR, Rrig, [-90.0, 1.0, 2.0])
         rectify_maps(1920, 1080, KL, dL, KR, dR, pl, pr, device=local)
         *_, rect_ms = rectify_maps(1920, 1080, KL, dL, KR, dR, pl, pr, device=local, return_ms=True)
@@ -375,7 +475,7 @@ def main():
                 "gpu_points_per_s": len(tgt) / t_est}
             ptree = po.KDTree(tgt)
             t0 = time.perf_counter()
-            rp = po.icp_point2point(ptree, src, 5, faithful=True, threads=1, history=False)
+            po.icp_point2point(ptree, src, 5, faithful=True, threads=1, history=False)
             neighbours["point_to_point"]["cpu_baseline"] = {
                 "value": 5 / (time.perf_counter() - t0), "unit": "iters/s", "cores": 1, "kind": "port",
                 "sample": "5 iterations of the same pair, tree build excluded"}
@@ -435,37 +535,72 @@ def main():
                             "one independent pair per GPU",
                 "points": n, "iters_per_step": args.iters,
             },
+            # the dominant kernel in the regime the byte model describes: a launch that searches
+            # (nearly) every point does the per-point work of the model once per point
             "roofline": {
-                "bound": "hbm", "kernel": "icp_iterate_kernel",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "bound": "hbm", "kernel": "icp_iterate_kernel, launches that search >= 90 % of the points",
+                "achieved": achieved_full, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_full / HBM_PEAK_GBS,
+                "traffic": traffic_full, "traffic_source": traffic_src,
+                "bytes_per_launch": bytes_fused, "launch_ms": full_ms, "units_per_launch": n,
+                "launch_ms_method": "HIP events on the launch stream around each eager launch, minus an "
+                                    "empty event pair; mean over the launches of this regime",
+                "launches_of_this_regime_per_step": int(full.sum()),
+                "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": achieved_full / stream_copy_gbs,
+                "bound_in_practice": "the gather path (see roofline_correspondence.own_loads_ms), not HBM",
+            },
+            # every launch of the timed region averaged, against the same algorithmic bytes: what
+            # the figure called `roofline` was before the regimes were split
+            "roofline_effective": {
+                "bound": "hbm", "kernel": "icp_iterate_kernel, all launches of the timed region",
+                "achieved": achieved_blend, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_blend / HBM_PEAK_GBS, "traffic": traffic_blend,
+                "traffic_source": traffic_blend_src,
                 "bytes_per_launch": bytes_fused, "launch_ms": launch_region_ms,
                 "launch_ms_method": "HIP events on the launch stream around the whole timed region "
-                                    "/ (steps x iterations)",
-                "eager_launch_ms_between_events": raw_ms, "empty_event_pair_ms": pair_ms,
-                "eager_launch_ms_minus_empty_pair": fused_ms,
+                                    "/ (steps x iterations); gaps between launches included",
                 "launches_averaged": args.steps * args.iters,
-                "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": achieved / stream_copy_gbs,
-                "loop_ms_per_iteration": elapsed / args.steps / args.iters * 1e3,
-                "slowest_launch_ms": slowest_ms,
-                "frac_slowest_launch": bytes_fused / (slowest_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "most launches skip the tiles whose points no longer move: not a bandwidth fraction",
+            },
+            # a settled launch: about 900 of 1024 tiles exit after reading their coordinates
+            "roofline_settled": {
+                "bound": "latency", "kernel": "icp_iterate_kernel, launches that search < 0.1 % of the points",
+                "launch_ms": settled_ms, "traffic": traffic_settled, "traffic_source": traffic_src,
+                "achieved": (traffic_settled or 0.0) / (settled_ms * 1e-3) / 1e9 if traffic_settled else None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ((traffic_settled / (settled_ms * 1e-3) / 1e9) / HBM_PEAK_GBS) if traffic_settled else None,
+                "launches_of_this_regime_per_step": int(settled.sum()),
+                "where_the_time_goes_us": {"kernel boundary": 2.7, "redundant solve": 1.6,
+                                           "tiles that still have work": 3.5,
+                                           "source": "per-block stamps of a trace build (DESIGN.md section 6)"},
             },
             # the standalone correspondence kernel (the reduction has no kernel of its own: it is
-            # fused into icp_iterate_kernel, whose roofline is the object above)
+            # fused into icp_iterate_kernel)
             "roofline_correspondence": {
                 "bound": "hbm", "kernel": "nn1_kernel<false>", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                 "achieved": bytes_nn / (nn_capped_ms * 1e-3) / 1e9,
                 "frac": bytes_nn / (nn_capped_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "bytes_per_launch": bytes_nn, "launch_ms": nn_capped_ms,
-                "note": "20 B per query + 16 B per target point; the kernel is bound by its gather "
-                        "instructions (texture-address units), not by HBM",
+                # the kernel's vector-memory instructions alone (same look-ups, same candidate
+                # loads, no arithmetic, nothing written): the floor of a per-lane gather search
+                "own_loads_ms": loads_ms, "own_loads_wave_instructions": loads_instr,
+                "frac_of_own_loads": loads_ms / nn_capped_ms,
+                "gather_path_wave_instructions_per_s": loads_instr / (loads_ms * 1e-3),
+                "hashed_loads_wave_instructions_per_s": hashed_instr / (hashed_ms * 1e-3),
+                "note": "20 B per query + 16 B per target point; bound by the texture-address path "
+                        "(one 16-byte gather per candidate per lane), not by HBM: the search runs at "
+                        "frac_of_own_loads of the speed of its own loads",
             },
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
             "kernels_ms": {"icp_iterate": fused_ms,
                            "icp_iterate_per_iteration": [round(float(x), 5) for x in per_iter],
-                           "nn1_capped": nn_capped_ms, "nn1_exact": nn_exact_ms},
+                           "searched_points_per_iteration": [int(x) for x in searched],
+                           "nn1_capped": nn_capped_ms, "nn1_exact": nn_exact_ms,
+                           "eager_launch_ms_between_events": raw_ms, "empty_event_pair_ms": pair_ms},
             "value_searching_every_point_every_iteration": full_search_value,
+            "value_inlier_pose": value_inlier_pose,
+            "value_sharded": value_sharded,
             "nn_queries_per_s": {"capped": n / (nn_capped_ms * 1e-3),
                                  "exact": n / (nn_exact_ms * 1e-3),
                                  "capped_GBs": bytes_nn / (nn_capped_ms * 1e-3) / 1e9,
@@ -479,9 +614,11 @@ def main():
             "sharded": sharded,
             "batched": batched,
             "calibration": calibration,
+            "dropin": dropin,
             "neighbouring_rows": neighbours,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if distributed:
         dist.destroy_process_group()

@@ -18,7 +18,11 @@ public:
         m_status = svicp_create(0, &m_ctx);
         for (int i = 0; i < 16; ++i) m_T[i] = (i % 5 == 0) ? 1.0 : 0.0;
     }
-    ~CPoint2PlaneICP() { svicp_destroy(m_ctx); }
+    ~CPoint2PlaneICP()
+    {
+        if (m_pinned) svicp_host_unregister(m_pinned);
+        svicp_destroy(m_ctx);
+    }
     CPoint2PlaneICP(const CPoint2PlaneICP &) = delete;
     CPoint2PlaneICP &operator=(const CPoint2PlaneICP &) = delete;
 
@@ -36,7 +40,16 @@ public:
         m_status = m_ctx ? svicp_set_target(m_ctx, ref.ptr(), (int64_t)ref.rows, normals.ptr())
                          : SVICP_ERR_NO_DEVICE;
     }
-    void setMoveData(flann::Matrix<float> move) { m_moveData = move; }   // :19-22, a view
+    // :19-22, a view.  run() copies the buffer to the device and back on every call, so a
+    // large one is pinned in place here (an addition; it stays the caller's memory)
+    void setMoveData(flann::Matrix<float> move)
+    {
+        if (m_pinned) { svicp_host_unregister(m_pinned); m_pinned = nullptr; }
+        m_moveData = move;
+        const int64_t bytes = (int64_t)move.rows * 3 * (int64_t)sizeof(float);
+        if (m_ctx && move.ptr() && bytes >= (1 << 20) && svicp_host_register(move.ptr(), bytes) == SVICP_OK)
+            m_pinned = move.ptr();
+    }
     void setEpsilon(float eps) { m_eps = eps; }                          // :23-26, never read
     void setMaxIterateCount(int count) { m_count = count; }              // :27-30
 
@@ -91,6 +104,7 @@ private:
     float m_eps;
     int m_count;
     svicp_ctx *m_ctx;
+    float *m_pinned = nullptr;
     int m_status;
     svicp_info m_info;
     double m_T[16];

@@ -9,8 +9,21 @@
 #include <vector>
 
 #include "flann_matrix.hpp"
+#include "svicp.h"
 
 class CTxtReader {
+    // The clouds are handed to the GPU (and the move data back) on every run(): they are
+    // allocated in pinned host memory when the library can provide it, so that those copies
+    // run at the speed of the link; plain new[] otherwise.  Never freed, as in the reference
+    // (CTxtReader.cpp:52).
+    static float *cloud_buffer(size_t floats)
+    {
+        void *p = nullptr;
+        if (floats >= (1u << 18) && svicp_host_alloc((int64_t)(floats * sizeof(float)), &p) == SVICP_OK && p)
+            return static_cast<float *>(p);
+        return new float[floats ? floats : 1];
+    }
+
 public:
     CTxtReader() {}
     virtual ~CTxtReader() {}
@@ -31,7 +44,7 @@ public:
             }
         }
         size_t rows = values.size() / 3;
-        float *buf = new float[values.size() ? values.size() : 1];
+        float *buf = cloud_buffer(values.size());
         for (size_t i = 0; i < values.size(); ++i) buf[i] = values[i];
         return flann::Matrix<float>(buf, rows, 3);
     }
@@ -46,7 +59,7 @@ public:
         if (!f.is_open()) return data;
         const std::streamoff bytes = f.tellg();
         const size_t rows = (size_t)bytes / (3 * sizeof(float));
-        float *buf = new float[rows ? rows * 3 : 1];
+        float *buf = cloud_buffer(rows * 3);
         f.seekg(0);
         f.read(reinterpret_cast<char *>(buf), (std::streamsize)(rows * 3 * sizeof(float)));
         return flann::Matrix<float>(buf, rows, 3);

@@ -107,6 +107,21 @@ int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n);
  * (CPoint2PlaneICP.cpp:42-50).  n x 3 fp32, caller order. */
 int svicp_get_source(svicp_ctx *ctx, float *xyz_aos_out);
 
+/* Pins a caller's host buffer in place (page-locks it and maps it for the device) so
+ * that svicp_set_source, svicp_get_source, svicp_set_target and svicp_knn copy it at the
+ * speed of the link instead of through the runtime's staging of pageable memory: worth it
+ * for a buffer that is handed over more than once (the move data of CPoint2PlaneICP, which
+ * run() reads and writes back on every call, CPoint2PlaneICP.cpp:42-50).  Registration
+ * itself costs about as much as one pageable copy.  Unregister before the buffer is freed.
+ * Not every system lets a process pin memory it did not allocate through the runtime
+ * (SVICP_ERR_HIP then, and the copies take the pageable path as before); memory from
+ * svicp_host_alloc is pinned from the start and always works: the drop-in CTxtReader
+ * allocates its clouds with it.  Errors: svicp_last_error(NULL). */
+int svicp_host_register(void *host_ptr, int64_t bytes);
+int svicp_host_alloc(int64_t bytes, void **out);
+int svicp_host_free(void *host_ptr);
+int svicp_host_unregister(void *host_ptr);
+
 /* ---- registration ---------------------------------------------------- */
 
 /* CPoint2PlaneICP::setMaxIterateCount + run (CPoint2PlaneICP.cpp:27-62).

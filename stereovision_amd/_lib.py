@@ -56,6 +56,10 @@ SYMBOLS = {
     "svicp_get_normals": (C.c_int, [_ctx, _fp]),
     "svicp_set_source": (C.c_int, [_ctx, _fp, C.c_int64]),
     "svicp_get_source": (C.c_int, [_ctx, _fp]),
+    "svicp_host_register": (C.c_int, [C.c_void_p, C.c_int64]),
+    "svicp_host_unregister": (C.c_int, [C.c_void_p]),
+    "svicp_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "svicp_host_free": (C.c_int, [C.c_void_p]),
     "svicp_run": (C.c_int, [_ctx, C.c_int, _dp, C.POINTER(Info)]),
     "svicp_run_enqueue": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "svicp_last_iterations": (C.c_int, [_ctx, C.POINTER(C.c_int)]),

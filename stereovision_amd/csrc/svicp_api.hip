@@ -1007,10 +1007,10 @@ int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n)
                 HIPCHK(ctx->scr->vals_a.reserve(sizeof(int) * nn));
                 hipLaunchKernelGGL(morton_key_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
                                    ctx->scr->tmp_aos.as<float>(), (int)n, mn[0], mn[1], mn[2],
-                                   2097151.0f / ext, ctx->scr->keys_a.as<unsigned long long>(),
+                                   (float)kMortonMax / ext, ctx->scr->keys_a.as<unsigned long long>(),
                                    ctx->scr->vals_a.as<int>());
                 LAUNCHCHK("morton_key_kernel");
-                rc = sort_pairs(ctx, n, 63);
+                rc = sort_pairs(ctx, n, 3 * kMortonBits);
                 if (rc) return rc;
                 void *before = ctx->perm.p;
                 HIPCHK(ctx->perm.reserve(sizeof(int) * nn));
@@ -1031,6 +1031,50 @@ int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n)
     ctx->have_source = true;
     ctx->total_points = 0;          // a sharded run agrees on the total again
     return update_fixed_point(ctx);
+}
+
+int svicp_host_alloc(int64_t bytes, void **out)
+{
+    if (!out || bytes <= 0) return fail(nullptr, SVICP_ERR_ARG, "svicp_host_alloc: bad argument");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return fail(nullptr, SVICP_ERR_HIP, "hipHostMalloc", e); }
+    return SVICP_OK;
+}
+
+int svicp_host_free(void *host_ptr)
+{
+    if (!host_ptr) return SVICP_OK;
+    hipError_t e = hipHostFree(host_ptr);
+    if (e != hipSuccess) return fail(nullptr, SVICP_ERR_HIP, "hipHostFree", e);
+    return SVICP_OK;
+}
+
+int svicp_host_register(void *host_ptr, int64_t bytes)
+{
+    if (!host_ptr || bytes <= 0) return fail(nullptr, SVICP_ERR_ARG, "svicp_host_register: bad argument");
+    hipError_t e = hipHostRegister(host_ptr, (size_t)bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        // whole pages: the pages that hold the buffer's first and last bytes are the caller's too
+        (void)hipGetLastError();
+        const uintptr_t page = 4096, lo = (uintptr_t)host_ptr & ~(page - 1),
+                        hi = ((uintptr_t)host_ptr + (uintptr_t)bytes + page - 1) & ~(page - 1);
+        e = hipHostRegister((void *)lo, (size_t)(hi - lo), hipHostRegisterDefault);
+    }
+    if (e != hipSuccess) return fail(nullptr, SVICP_ERR_HIP, "hipHostRegister", e);
+    return SVICP_OK;
+}
+
+int svicp_host_unregister(void *host_ptr)
+{
+    if (!host_ptr) return SVICP_OK;
+    hipError_t e = hipHostUnregister(host_ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipHostUnregister((void *)((uintptr_t)host_ptr & ~(uintptr_t)4095));
+    }
+    if (e != hipSuccess) return fail(nullptr, SVICP_ERR_HIP, "hipHostUnregister", e);
+    return SVICP_OK;
 }
 
 int svicp_get_source(svicp_ctx *ctx, float *xyz_aos_out)

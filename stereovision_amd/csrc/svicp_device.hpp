@@ -2229,7 +2229,11 @@ __device__ __forceinline__ unsigned long long spread21(unsigned v)
     return x;
 }
 
-// Morton key of each source point over the source's own bounding box
+// Morton key of each source point over the source's own bounding box: kMortonBits per axis
+// (8192 steps: far finer than the spacing of any cloud dense enough to fill a tile, and the
+// sort's cost goes with the number of key bits)
+constexpr int kMortonBits = 13;
+constexpr int kMortonMax = (1 << kMortonBits) - 1;
 __global__ void morton_key_kernel(const float *__restrict__ aos, int n, float ox, float oy,
                                   float oz, float scale, unsigned long long *__restrict__ keys,
                                   int *__restrict__ vals)
@@ -2238,7 +2242,7 @@ __global__ void morton_key_kernel(const float *__restrict__ aos, int n, float ox
     if (i >= n) return;
     auto q = [&](float v, float o) {
         float f = (v - o) * scale;
-        f = fminf(fmaxf(f, 0.f), 2097151.f);
+        f = fminf(fmaxf(f, 0.f), (float)kMortonMax);
         return (unsigned)f;
     };
     keys[i] = spread21(q(aos[3 * (size_t)i], ox)) | (spread21(q(aos[3 * (size_t)i + 1], oy)) << 1) |

@@ -33,6 +33,56 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def host_register(array):
+    """Pins a numpy array in place (svicp_host_register); pair with host_unregister."""
+    lib = _lib.load()
+    rc = lib.svicp_host_register(C.c_void_p(array.ctypes.data), array.nbytes)
+    if rc != 0:
+        raise SvicpError(rc, lib.svicp_last_error(None).decode())
+
+
+def host_unregister(array):
+    lib = _lib.load()
+    rc = lib.svicp_host_unregister(C.c_void_p(array.ctypes.data))
+    if rc != 0:
+        raise SvicpError(rc, lib.svicp_last_error(None).decode())
+
+
+class _PinnedBlock:
+    """Owner of one svicp_host_alloc block; numpy views keep it alive through .base."""
+
+    def __init__(self, nbytes):
+        self._lib = _lib.load()
+        p = C.c_void_p()
+        rc = self._lib.svicp_host_alloc(int(nbytes), C.byref(p))
+        if rc != 0:
+            raise SvicpError(rc, self._lib.svicp_last_error(None).decode())
+        self.ptr, self.nbytes = p.value, int(nbytes)
+        self.buffer = (C.c_char * self.nbytes).from_address(self.ptr)
+
+    def __del__(self):
+        try:
+            self._lib.svicp_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """A numpy array in pinned host memory (svicp_host_alloc): clouds kept in such arrays go
+    to the device and back at the speed of the link."""
+    shape = tuple(int(x) for x in np.atleast_1d(shape))
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    block = _PinnedBlock(max(n, 1))
+    arr = np.frombuffer(block.buffer, dtype=dtype, count=int(np.prod(shape))).reshape(shape).view(_PinnedArray)
+    arr._block = block          # views of `arr` keep `arr` (their base) and with it the block alive
+    return arr
+
+
+class _PinnedArray(np.ndarray):
+    """ndarray over a _PinnedBlock; the only addition is the reference that keeps the block."""
+    _block = None
+
+
 class Context:
     """One svicp_ctx: a target grid, a resident source and the iteration state."""
 
@@ -421,7 +471,27 @@ class CPoint2PlaneICP:
                 and move.ndim == 2 and move.shape[1] == 3 and move.flags.c_contiguous):
             raise ValueError("setMoveData: pass a C-contiguous (N, 3) float32 array; "
                              "run() updates it in place")
+        self._unpin()
         self._move = move
+        if move.nbytes >= self.PIN_FROM_BYTES:
+            try:
+                host_register(move)
+                self._pinned = move
+            except SvicpError:
+                self._pinned = None            # (not pinnable: the copies take the pageable path)
+
+    PIN_FROM_BYTES = 1 << 20    # run() copies the buffer in and out on every call: pin what is large
+
+    def _unpin(self):
+        if getattr(self, "_pinned", None) is not None:
+            try:
+                host_unregister(self._pinned)
+            except SvicpError:
+                pass
+            self._pinned = None
+
+    def __del__(self):
+        self._unpin()
 
     def setEpsilon(self, eps):
         self.m_eps = float(eps)            # stored and never read, as in the reference

@@ -1,18 +1,24 @@
 #!/bin/bash
 # One GPU call: tests, benchmark, rocprofv3 kernel statistics of the same benchmark command, and
-# the two HBM counter passes.  Every step under its own time limit; stops at the first failure.
+# the counter passes (each a run of its own over tools/profile_step.py).  Every step under its
+# own time limit; stops at the first failure.  Summaries land in gpurun_out/round/ and are
+# copied to profiles/ by hand.
 set -e
+TAG=${1:-r02}
 O=gpurun_out/round
 rm -rf $O && mkdir -p $O
 R=$PWD
-timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > $O/tests.log 2>&1
-timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $O/tests.log 2>&1
+timeout -k 10 400 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats -o stats -- python3 $R/bench.py --cpu-iters 0 > $R/$O/bench_under_rocprof.json 2> $R/$O/rocprof.err
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/fetch -o fetch -- python3 $R/bench.py --steps 3 --warmup 1 --sharded-side 0 --cpu-iters 0 --cal-views 0 --batch-pairs 0 --extras 0 > /dev/null 2> $R/$O/fetch.err
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/write -o write -- python3 $R/bench.py --steps 3 --warmup 1 --sharded-side 0 --cpu-iters 0 --cal-views 0 --batch-pairs 0 --extras 0 > /dev/null 2> $R/$O/write.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats -o stats -- python3 $R/bench.py --cpu-iters 0 > $R/$O/${TAG}_bench_under_rocprof.json 2> $R/$O/rocprof.err
+P="python3 $R/tools/profile_step.py"
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/p1 -o p -- $P > /dev/null 2> $R/$O/p1.err
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/p2 -o p -- $P > /dev/null 2> $R/$O/p2.err
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_VALU --output-format csv -d $R/$O/p3 -o p -- $P > /dev/null 2> $R/$O/p3.err
+timeout -s KILL 120 rocprofv3 --pmc TA_TA_BUSY_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $R/$O/p4 -o p -- $P > /dev/null 2> $R/$O/p4.err
 cd $R
-python tools/summarise_profiles.py stats $O/stats $O/r01 
-python tools/summarise_profiles.py traffic $O/fetch $O/write $O/r01_traffic.json 54525952
-rm -rf $O/stats $O/fetch $O/write
-tail -3 $O/tests.log
+python tools/summarise_profiles.py stats $O/stats $O/$TAG
+python tools/summarise_profiles.py regimes $O/${TAG}_counters.json $O/${TAG}_traffic.json $O/p1 $O/p2 $O/p3 $O/p4
+rm -rf $O/stats $O/p1 $O/p2 $O/p3 $O/p4
+tail -n 3 $O/tests.log
