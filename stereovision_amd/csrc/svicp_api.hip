@@ -114,7 +114,7 @@ struct ScopedEvent {
 // history, the tiles' "had work" flags.  Sized for kEnqMaxIters iterations of a source of
 // kEnqMaxTiles tiles (1024 points each).
 constexpr int kEnqMaxIters = 128;
-constexpr int kEnqMaxTiles = 4096;
+constexpr int kEnqMaxTiles = 4194304 / kItTile;
 constexpr size_t enq_align(size_t b) { return (b + 255) & ~(size_t)255; }
 constexpr size_t kEnqOffState = 0;
 constexpr size_t kEnqOffTotals = kEnqOffState + enq_align(sizeof(IcpState));
@@ -122,7 +122,7 @@ constexpr size_t kEnqOffDeltas = kEnqOffTotals + enq_align(sizeof(double) * kNum
 constexpr size_t kEnqOffXhist = kEnqOffDeltas + enq_align(sizeof(double) * kDeltaRow * (kEnqMaxIters + 1));
 constexpr size_t kEnqOffIhist = kEnqOffXhist + enq_align(sizeof(double) * 6 * kEnqMaxIters);
 constexpr size_t kEnqOffFlags = kEnqOffIhist + enq_align(sizeof(double) * 4 * kEnqMaxIters);
-constexpr size_t kEnqOffPartials = kEnqOffFlags + enq_align(2 * kFlagCap);
+constexpr size_t kEnqOffPartials = kEnqOffFlags + enq_align(sizeof(unsigned long long) * kFlagRows * kFlagWords);
 constexpr size_t kEnqBytes = kEnqOffPartials + enq_align(sizeof(double) * kNumSums * kEnqMaxTiles);
 static __device__ __align__(256) unsigned char scratch[kEnqBytes];   // about 1.2 MB
 
@@ -170,7 +170,7 @@ struct svicp_ctx {
     int cur = 0;   // 0: the pristine copy is current, 1: the work copy
     DevBuf sx0, sy0, sz0, wx, wy, wz, perm;
     DevBuf st_tp, st_nv, st_lb;   // per source point: matched target point, normal, bound
-    DevBuf tile_flags;            // [2][kFlagCap] bytes: which tiles had work in the last two iterations
+    DevBuf tile_flags;            // [kFlagRows][kFlagWords] 64-bit words: which tiles had work in the last iterations
 
 
     // iteration loop
@@ -227,7 +227,8 @@ struct svicp_batch {
     std::vector<unsigned char> sent_pairs, sent_map;   // what the device tables hold
     IcpState *h_states = nullptr;       // pinned
     int total_blocks = 0;
-    int iters_cap = 0;
+    int iters_cap = 0;                  // iterations the pairs' buffers hold (see svicp_batch_run)
+    bool tables_ready = false;
     hipGraphExec_t gexec = nullptr;
     int g_iters = -1;
     bool g_coherent = true;             // the option the captured graph was built with
@@ -447,8 +448,8 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
     ctx->nb = nb; ctx->chunk = chunk;
     HIPCHK(ctx->partials.reserve(sizeof(double) * kNumSums * nb));
     if (!ctx->tile_flags.p) {
-        HIPCHK(ctx->tile_flags.reserve(2 * kFlagCap));
-        HIPCHK(hipMemsetAsync(ctx->tile_flags.p, 0, 2 * kFlagCap, ctx->stream));
+        HIPCHK(ctx->tile_flags.reserve(sizeof(unsigned long long) * kFlagRows * kFlagWords));
+        HIPCHK(hipMemsetAsync(ctx->tile_flags.p, 0, sizeof(unsigned long long) * kFlagRows * kFlagWords, ctx->stream));
     }
     HIPCHK(ctx->state.reserve(sizeof(IcpState)));
     if (iters > ctx->hist_cap) {
@@ -478,7 +479,7 @@ struct LoopBufs {
     double *partials, *xhist, *ihist;
     fx_t *totals, *deltas;
     IcpState *state;
-    unsigned char *flags;    // [2][kFlagCap] or null
+    unsigned long long *flags;    // [kFlagRows][kFlagWords] or null
 };
 
 LoopBufs own_bufs(svicp_ctx *ctx)
@@ -490,7 +491,7 @@ LoopBufs own_bufs(svicp_ctx *ctx)
     b.xhist = ctx->xhist.as<double>();
     b.ihist = ctx->ihist.as<double>();
     b.state = ctx->state.as<IcpState>();
-    b.flags = ctx->nb <= kFlagCap ? ctx->tile_flags.as<unsigned char>() : nullptr;
+    b.flags = ctx->nb <= kFlagCap ? ctx->tile_flags.as<unsigned long long>() : nullptr;
     return b;
 }
 
@@ -1188,7 +1189,7 @@ int svicp_run_enqueue(svicp_ctx *ctx, int iterations, double *dev_out20)
     b.deltas = reinterpret_cast<fx_t *>(w + kEnqOffDeltas);
     b.xhist = reinterpret_cast<double *>(w + kEnqOffXhist);
     b.ihist = reinterpret_cast<double *>(w + kEnqOffIhist);
-    b.flags = nb <= kFlagCap ? w + kEnqOffFlags : nullptr;
+    b.flags = nb <= kFlagCap ? reinterpret_cast<unsigned long long *>(w + kEnqOffFlags) : nullptr;
     b.partials = reinterpret_cast<double *>(w + kEnqOffPartials);
     // The array keeps the last call's contents.  What a run takes to be zero when it starts:
     // row 0 of the totals and rows 0 and 1 of the per-iteration changes (every later row is
@@ -1849,6 +1850,16 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
     HIPCHK(hipSetDevice(ctx->device));
     const int count = (int)b->ctxs.size();
 
+    // A batch built from arrays owns its pairs and nobody can give them other clouds or
+    // buffers: once its tables are on the device and its buffers hold `iters_cap` iterations
+    // a run has nothing to prepare (512 pairs: 0.3 - 3 ms of host time per run otherwise).
+    const bool coherent = ctx->opt.coherent != 0;
+    const bool prepared = b->owns && b->tables_ready && iterations <= b->iters_cap;
+    if (prepared && (b->g_iters != iterations || b->g_coherent != coherent)) {
+        if (b->gexec) { (void)hipGraphExecDestroy(b->gexec); b->gexec = nullptr; }
+        b->g_iters = -1;
+    }
+    if (!prepared) {
     // (re)build the device tables when any pair's buffers changed
     std::vector<BatchPair> hp(count);
     std::vector<int2> map;
@@ -1901,14 +1912,18 @@ int svicp_batch_run(svicp_batch *b, int iterations, double *T_out, svicp_info *i
         b->sent_pairs.assign(hb, hb + hsize);
         b->sent_map.assign(mbytes, mbytes + msize);
     }
-    const bool coherent = ctx->opt.coherent != 0;
-    const int total = (int)map.size();
-    if (pb != b->pairs.p || mb != b->block_map.p || rb != b->rt_all.p || total != b->total_blocks ||
+    const int total_now = (int)map.size();
+    if (pb != b->pairs.p || mb != b->block_map.p || rb != b->rt_all.p || total_now != b->total_blocks ||
         b->g_iters != iterations || b->g_coherent != coherent) {
         if (b->gexec) { (void)hipGraphExecDestroy(b->gexec); b->gexec = nullptr; }
         b->g_iters = -1;
     }
-    b->total_blocks = total;
+    b->total_blocks = total_now;
+    b->tables_ready = true;
+    b->iters_cap = b->ctxs[0]->hist_cap;
+    for (svicp_ctx *c : b->ctxs) b->iters_cap = std::min(b->iters_cap, c->hist_cap);
+    }
+    const int total = b->total_blocks;
 
     auto enqueue = [&]() -> int {
         const BatchPair *dp = b->pairs.as<BatchPair>();

@@ -489,11 +489,13 @@ struct PointState {
     Float3 *tp;       // matched target point; x is NaN when there is none within cov
     Float3 *nv;       // its normal
     float *lb;
-    // [2][kFlagCap] bytes or null: bit 0 of byte t of row (k & 1) says whether tile t had
-    // work to do in iteration k (see choose_tile)
-    unsigned char *active;
+    // [3][64] words of 64 bits or null: bit (t mod 64) of word (t / 64) of row (k mod 3) says
+    // whether tile t had work to do in iteration k (see choose_tile).  A row is written in
+    // iteration k (atomic OR by the tiles with work), read in k + 1 and cleared in k + 2.
+    unsigned long long *active;
 };
-constexpr int kFlagCap = 1024;   // tiles the adaptive block order handles (16 per lane of a wave)
+constexpr int kFlagCap = 4096;   // tiles the adaptive block order handles (64 per lane of a wave)
+constexpr int kFlagRows = 3, kFlagWords = kFlagCap / 64;
 
 // ------------------------------------------------------------------------
 // 6x6 solve and transform update on the device.
@@ -818,44 +820,46 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
 // one XCD, and the tiles without work take the rest.  With every tile active this is
 // xcd_contiguous itself.  Every wave of every block evaluates the same flags, so the
 // result is a permutation of the tiles.  `predicted`: the tile had work last time.
-// Position of the r-th (from 0) set bit of the 16-bit mask m; r < popcount(m).
-__device__ __forceinline__ int select16(unsigned m, int r)
+// Position of the r-th (from 0) set bit of the 64-bit mask m; r < popcount(m).
+__device__ __forceinline__ int select64(unsigned long long m, int r)
 {
     int pos = 0;
-    int c = __popc(m & 0xffu);
-    if (r >= c) { r -= c; pos += 8; m >>= 8; }
-    c = __popc(m & 0xfu);
-    if (r >= c) { r -= c; pos += 4; m >>= 4; }
-    c = __popc(m & 0x3u);
-    if (r >= c) { r -= c; pos += 2; m >>= 2; }
-    if (r >= (int)(m & 1u)) pos += 1;
+    int c = __popc((unsigned)m);
+    if (r >= c) { r -= c; pos += 32; m >>= 32; }
+    unsigned w = (unsigned)m;
+    c = __popc(w & 0xffffu);
+    if (r >= c) { r -= c; pos += 16; w >>= 16; }
+    c = __popc(w & 0xffu);
+    if (r >= c) { r -= c; pos += 8; w >>= 8; }
+    c = __popc(w & 0xfu);
+    if (r >= c) { r -= c; pos += 4; w >>= 4; }
+    c = __popc(w & 0x3u);
+    if (r >= c) { r -= c; pos += 2; w >>= 2; }
+    if (r >= (int)(w & 1u)) pos += 1;
     return pos;
 }
 
-__device__ __forceinline__ int choose_tile(const uint4 v, int nb, int b, bool &predicted,
+__device__ __forceinline__ int choose_tile(const unsigned long long bits, int nb, int b, bool &predicted,
                                            int &n_predicted)
 {
-    const int lane = threadIdx.x & 63;                             // v: the flag bytes of 16 tiles
-    // bit 0 of byte k of a word to bit k of a nibble: the products land on distinct bits
-    auto nib = [](unsigned w) { return (((w & 0x01010101u) * 0x01020408u) >> 24) & 0xfu; };
-    const int valid = min(max(nb - 16 * lane, 0), 16);             // tiles past the end: neither kind
-    const unsigned in_range = (1u << valid) - 1u;
-    const unsigned bits = nib(v.x) | (nib(v.y) << 4) | (nib(v.z) << 8) | (nib(v.w) << 12);
-    const unsigned with_work = bits & in_range, without = ~bits & in_range;
-    const int cnt = __popc(with_work);
+    const int lane = threadIdx.x & 63;                             // bits: the flags of tiles 64 lane .. 64 lane + 63
+    const int valid = min(max(nb - 64 * lane, 0), 64);             // tiles past the end: neither kind
+    const unsigned long long in_range = valid >= 64 ? ~0ull : (1ull << valid) - 1ull;
+    const unsigned long long with_work = bits & in_range, without = ~bits & in_range;
+    const int cnt = __popcll(with_work);
     const int inc = wave_inclusive_scan(cnt);
     const int A = __builtin_amdgcn_readlane(inc, 63);
     n_predicted = A;
     predicted = b < A;
     // the j-th tile with (predicted) or without work: lane L holds it
     const int j = predicted ? xcd_contiguous(b, A) : b - A;
-    const int mine = predicted ? inc : min(16 * (lane + 1), nb) - inc;   // inclusive count of my kind
-    const unsigned kind = predicted ? with_work : without;
-    const int pos = select16(kind, max(j - (mine - (int)__popc(kind)), 0));   // meaningful in lane L only
+    const int mine = predicted ? inc : min(64 * (lane + 1), nb) - inc;   // inclusive count of my kind
+    const unsigned long long kind = predicted ? with_work : without;
+    const int pos = select64(kind, max(j - (mine - (int)__popcll(kind)), 0));   // meaningful in lane L only
     const unsigned long long m = __ballot(mine > j);
     if (m == 0ull) return xcd_contiguous(b, nb);                   // cannot happen: j < count
     const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
-    const int tile = 16 * L + __builtin_amdgcn_readlane(pos, L);
+    const int tile = 64 * L + __builtin_amdgcn_readlane(pos, L);
     return tile < nb ? tile : xcd_contiguous(b, nb);
 }
 
@@ -901,8 +905,8 @@ __device__ __forceinline__ void iterate_tile(
     if (APPLY && CERTIFY && fixed_tile < 0) {
         bool predicted;
         int n_predicted;
-        tile = choose_tile(reinterpret_cast<const uint4 *>(ps.active + (size_t)((iter - 1) & 1) * kFlagCap)[lane],
-                           nb, (int)blockIdx.x, predicted, n_predicted);
+        tile = choose_tile(ps.active[((iter - 1) % kFlagRows) * kFlagWords + lane], nb, (int)blockIdx.x,
+                           predicted, n_predicted);
         // while most tiles still have work the points move too far for the remembered
         // correspondences to be of use
         prefetch = predicted && 4 * n_predicted <= nb;
@@ -938,9 +942,12 @@ __device__ __forceinline__ void iterate_tile(
     }
     // the next iteration's delta row starts at zero (the buffer holds one row more
     // than the longest run; row 0 is cleared by the kernel that ends a run)
-    if (tile == 0)
+    if (tile == 0) {
         for (int k = threadIdx.x; k < kDeltaRow; k += kItThreads)
             deltas[(size_t)(iter + 1) * kDeltaRow + k] = 0;
+        // and the flag row the next iteration will write (last read in the iteration before this one)
+        if (ps.active && threadIdx.x < kFlagWords) ps.active[((iter + 1) % kFlagRows) * kFlagWords + threadIdx.x] = 0ull;
+    }
 
     // ---- B: the first wave solves the previous iteration's system.  Meanwhile, in a tile
     // that is expected to have work (it had some in the iteration before), the other waves
@@ -1025,14 +1032,11 @@ __device__ __forceinline__ void iterate_tile(
     // only the coordinates had to be read.  Near convergence most tiles are
     // like that. ----
     SVICP_STAMP(2);
-    unsigned char *const flag = ps.active ? ps.active + (size_t)(iter & 1) * kFlagCap + tile : nullptr;
     if (APPLY && CERTIFY && in_place) {
-        if (!__syncthreads_or(any_moved ? 1 : 0)) {
-            if (flag && threadIdx.x == 0) *flag = 0;
-            return;
-        }
+        if (!__syncthreads_or(any_moved ? 1 : 0)) return;      // (its flag bit stays clear)
     }
-    if (flag && threadIdx.x == 0) *flag = 1;
+    // (the tile's flag bit is raised at the very end: an atomic stays in the wave's count of
+    // outstanding memory operations for microseconds, and every later load would wait behind it)
     SVICP_STAMP(3);
 
     double acc[30];
@@ -1116,12 +1120,6 @@ __device__ __forceinline__ void iterate_tile(
     }
     if (total > 0) __syncthreads();     // (the same in every thread)
 
-    // slot 31 of the iteration's delta row counts the searched points (a statistic
-    // for the caller; the solve reads slots 0..29 only)
-    if (threadIdx.x == 0 && total > 0)
-        atomicAdd(reinterpret_cast<unsigned long long *>(deltas) + (size_t)iter * kDeltaRow +
-                      (tile & (kDeltaCopies - 1)) * kNumSums + 31,
-                  (unsigned long long)total);
 
     SVICP_STAMP(5);
     // ---- G: search the queued points (CPoint2PlaneICP.cpp:65-67) ----
@@ -1198,6 +1196,15 @@ __device__ __forceinline__ void iterate_tile(
                           (tile & (kDeltaCopies - 1)) * kNumSums + threadIdx.x,
                       (unsigned long long)d);
     }
+    // slot 31 of the iteration's delta row counts the searched points (a statistic for the
+    // caller; the solve reads slots 0..29 only).  Like every atomic of this kernel it is issued
+    // after the wave's last load.
+    if (threadIdx.x == 31 && total > 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(deltas) + (size_t)iter * kDeltaRow +
+                      (tile & (kDeltaCopies - 1)) * kNumSums + 31,
+                  (unsigned long long)total);
+    if (ps.active && threadIdx.x == 64)
+        atomicOr(ps.active + (iter % kFlagRows) * kFlagWords + (tile >> 6), 1ull << (tile & 63));
     SVICP_STAMP(7);
 }
 
@@ -1205,7 +1212,7 @@ template <bool APPLY, bool CERTIFY, int CH, bool INPLACE>
 __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     // what the first loads of a launch need comes first
     fx_t *__restrict__ totals, fx_t *__restrict__ deltas, const int *__restrict__ fx, int iter, int n,
-    unsigned char *ps_active, Float3 *ps_tp, Float3 *ps_nv, float *ps_lb,   // a PointState, member by member
+    unsigned long long *ps_active, Float3 *ps_tp, Float3 *ps_nv, float *ps_lb,   // a PointState, member by member
     const float *sx_in, const float *sy_in, const float *sz_in, float *sx_out, float *sy_out,
     float *sz_out, IcpState *st, double *X_hist, double *info_hist, CohParams cp,
     double *__restrict__ partials, GridDesc g)
