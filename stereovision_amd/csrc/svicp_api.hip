@@ -113,6 +113,8 @@ struct ScopedEvent {
 // the tiles' sums, the running totals and their per-iteration changes, the iteration state and
 // history, the tiles' "had work" flags.  Sized for kEnqMaxIters iterations of a source of
 // kEnqMaxTiles tiles (1024 points each).
+// from this many tiles on (four rounds of blocks on 256 compute units) the solve gets a launch of its own
+constexpr int kSolveApartTiles = 4096;
 constexpr int kEnqMaxIters = 128;
 constexpr int kEnqMaxTiles = 4194304 / kItTile;
 constexpr size_t enq_align(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -177,6 +179,7 @@ struct svicp_ctx {
     DevBuf partials, totals, deltas, state, xhist, ihist;
     // fixed-point exponents of the 30 sums (see update_fixed_point) and what they are made from
     DevBuf fx_exp;
+    DevBuf rt_apart;               // R, T handed from a solve launch to the iteration launch (many-tile sources)
     int fx_host[kNumSums] = {};
     float tgt_maxabs = 0.f, nrm_maxabs = 1.f;
     int64_t total_points = 0;      // source points over ALL ranks of a sharded run (0: this context's own)
@@ -336,6 +339,7 @@ int update_fixed_point(svicp_ctx *ctx)
     ctx->fx_host[29] = exponent(0, 0, 0);
     ctx->fx_host[30] = ctx->fx_host[31] = 0;
     HIPCHK(ctx->fx_exp.reserve(sizeof(int) * kNumSums));
+    HIPCHK(ctx->rt_apart.reserve(sizeof(double) * 16));
     HIPCHK(hipMemcpyAsync(ctx->fx_exp.p, ctx->fx_host, sizeof(int) * kNumSums, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SVICP_OK;
@@ -517,10 +521,25 @@ void launch_iteration(svicp_ctx *ctx, int k, const LoopBufs &b)
     double *partials = b.partials;
     const dim3 grid(ctx->nb), block(kItThreads);
     const int n = (int)ctx->n;
+    // Many thousands of tiles: the previous iteration's system is solved once, by a launch of
+    // its own, instead of by every block of every round (the tile that records is then the
+    // solve kernel's: the iteration kernel only reads R and T).
+    const bool apart = k >= 1 && ctx->nb >= kSolveApartTiles;
+    double *rt = ctx->rt_apart.as<double>();
+    if (apart)
+        hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, tot, del, fx, state, xh, ih, k - 1,
+                           (IcpState *)nullptr, (double *)nullptr, rt);
 #define SVICP_ITERATE(APPLY, CERTIFY, INPLACE, ix, iy, iz)                                        \
-    hipLaunchKernelGGL((icp_iterate_kernel<APPLY, CERTIFY, 4, INPLACE>), grid, block, 0, ctx->stream, \
-                       tot, del, fx, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, \
-                       xh, ih, cp, partials, ctx->g)
+    do {                                                                                          \
+        if (apart)                                                                                \
+            hipLaunchKernelGGL((icp_iterate_kernel<APPLY, CERTIFY, 4, INPLACE, true>), grid, block, 0, ctx->stream, \
+                               tot, del, fx, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, \
+                               xh, ih, cp, partials, ctx->g, rt);                                 \
+        else                                                                                      \
+            hipLaunchKernelGGL((icp_iterate_kernel<APPLY, CERTIFY, 4, INPLACE, false>), grid, block, 0, ctx->stream, \
+                               tot, del, fx, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, \
+                               xh, ih, cp, partials, ctx->g, (const double *)nullptr);            \
+    } while (0)
     // iteration 0 reads the source as set and moves nothing, iteration 1 reads it and writes
     // the moving copy, later ones update the moving copy where it is
     if (k == 0) SVICP_ITERATE(false, false, false, x0, y0, z0);
@@ -707,7 +726,7 @@ int svicp_destroy(svicp_ctx *ctx)
     DevBuf *bufs[] = { &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->quad, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx,
                        &ctx->wy, &ctx->wz, &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->tile_flags, &ctx->perm,
                        &ctx->partials, &ctx->totals, &ctx->deltas, &ctx->state, &ctx->xhist, &ctx->ihist,
-                       &ctx->p2p_sums, &ctx->rthist, &ctx->fx_exp };
+                       &ctx->p2p_sums, &ctx->rthist, &ctx->fx_exp, &ctx->rt_apart };
     for (DevBuf *b : bufs) b->release();          // (slices of an arena are the arena's to free)
     ctx->own_scr.release();
     if (ctx->h_state && ctx->h_state_pinned) (void)hipHostFree(ctx->h_state);
@@ -1790,7 +1809,7 @@ int svicp_batch_create_from_arrays(int device_id, int count, const int64_t *tgt_
         DevBuf *persistent[] = { &c->pts, &c->nrm, &c->dir, &c->quad, &c->sx0, &c->sy0, &c->sz0, &c->wx, &c->wy,
                                  &c->wz, &c->st_tp, &c->st_nv, &c->st_lb, &c->tile_flags, &c->perm, &c->partials,
                                  &c->totals, &c->deltas, &c->state, &c->xhist, &c->ihist, &c->p2p_sums,
-                                 &c->rthist, &c->fx_exp };
+                                 &c->rthist, &c->fx_exp, &c->rt_apart };
         for (DevBuf *d : persistent) d->arena = &b->arena;
         c->h_state = &b->host_states[i];
         c->h_state_pinned = false;

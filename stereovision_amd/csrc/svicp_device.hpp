@@ -1134,9 +1134,8 @@ __device__ __forceinline__ void iterate_tile(
         if (bpos >= 0 && sqrtf(best) * kSlackUp <= cp.cov) {
             // no unprobed point can be nearer: bpos is the nearest neighbour
             const float4 t = target_point();
-            const size_t o = 3 * (size_t)bpos;
             tp = { t.x, t.y, t.z };
-            nv = { g.nrm[o], g.nrm[o + 1], g.nrm[o + 2] };
+            nv = reinterpret_cast<const Float3 *>(g.nrm)[bpos];     // one 12-byte gather, not three of 4
             lbn = fminf(sqrtf(second) * kSlackDown, lbn);
             if (best <= cp.thr)
                 accumulate_point(acc, e.x, e.y, e.z, best, cp.thr, t.x, t.y, t.z, nv.x, nv.y, nv.z);
@@ -1208,14 +1207,17 @@ __device__ __forceinline__ void iterate_tile(
     SVICP_STAMP(7);
 }
 
-template <bool APPLY, bool CERTIFY, int CH, bool INPLACE>
+// SOLVE_APART: a solve_kernel launched before this one has left R and T at rt_given (sources
+// of many thousands of tiles: their blocks run in many rounds, and a solve of 1.6 us in every
+// block of every round costs more than one more launch).
+template <bool APPLY, bool CERTIFY, int CH, bool INPLACE, bool SOLVE_APART = false>
 __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     // what the first loads of a launch need comes first
     fx_t *__restrict__ totals, fx_t *__restrict__ deltas, const int *__restrict__ fx, int iter, int n,
     unsigned long long *ps_active, Float3 *ps_tp, Float3 *ps_nv, float *ps_lb,   // a PointState, member by member
     const float *sx_in, const float *sy_in, const float *sz_in, float *sx_out, float *sy_out,
     float *sz_out, IcpState *st, double *X_hist, double *info_hist, CohParams cp,
-    double *__restrict__ partials, GridDesc g)
+    double *__restrict__ partials, GridDesc g, const double *__restrict__ rt_given)
 {
     const int nb = (int)gridDim.x;
     PointState ps;
@@ -1224,7 +1226,8 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     iterate_tile<APPLY, CERTIFY, CH, INPLACE>(g, sx_in, sy_in, sz_in, sx_out, sy_out, sz_out, n,
                                               totals, deltas, fx, st, X_hist, info_hist, iter, cp, ps,
                                               partials,
-                                              adaptive ? -1 : xcd_contiguous((int)blockIdx.x, nb), nb);
+                                              adaptive ? -1 : xcd_contiguous((int)blockIdx.x, nb), nb,
+                                              /* solve_now = */ !SOLVE_APART, rt_given);
 }
 
 // ------------------------------------------------------------------------
@@ -1321,7 +1324,7 @@ constexpr int kRunOutDoubles = 20;
 __global__ __launch_bounds__(64) void solve_kernel(fx_t *totals, fx_t *deltas, const int *fx,
                                                    IcpState *st, double *X_hist,
                                                    double *info_hist, int iter, IcpState *host_copy,
-                                                   double *dev_out)
+                                                   double *dev_out, double *rt_out = nullptr)
 {
     __shared__ double rt[12];
     solve_and_update(request_sums(totals + (size_t)iter * kNumSums,
@@ -1329,6 +1332,11 @@ __global__ __launch_bounds__(64) void solve_kernel(fx_t *totals, fx_t *deltas, c
                      totals + (size_t)(iter + 1) * kNumSums, st, X_hist, info_hist, iter, true,
                      rt);
     __syncthreads();
+    if (rt_out) {
+        // between two iterations of a run: R and T for the next launch, nothing else
+        if (threadIdx.x < 12) rt_out[threadIdx.x] = rt[threadIdx.x];
+        return;
+    }
     // leave the first delta row clean for the next run, and hand the state to the
     // host through mapped memory (one store per lane instead of a copy command)
     for (int k = threadIdx.x; k < kDeltaRow; k += 64) deltas[k] = 0;
