@@ -32,12 +32,13 @@ def test_iteration_kernels_use_no_scratch(tmp_path):
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m and name:
             seen[name] = int(m.group(1))
-    # every variant of the single-pair kernel and the batch kernel in its usual form
+    # every variant of the single-pair kernel (five, each with the solve inside the launch and
+    # with the solve in a launch of its own) and the batch kernel in its usual form
     # (searching every point every iteration in a batch is a debugging option)
     single = {k: v for k, v in seen.items() if "18icp_iterate_kernel" in k}
     batch = {k: v for k, v in seen.items() if "24icp_iterate_batch_kernelILb1ELb1" in k
              or "24icp_iterate_batch_kernelILb0ELb0" in k}
     knn = {k: v for k, v in seen.items() if "15knn_wave_kernel" in k}
-    assert len(single) == 5 and len(batch) == 2 and len(knn) == 1, sorted(seen)
+    assert len(single) == 10 and len(batch) == 2 and len(knn) == 1, sorted(seen)
     spilling = {k: v for k, v in {**single, **batch, **knn}.items() if v != 0}
     assert not spilling, spilling
