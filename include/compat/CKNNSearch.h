@@ -10,9 +10,10 @@
 
 class CKNNSearch {
 public:
-    CKNNSearch() : m_k(1), m_ctx(nullptr), m_curRows(0), m_status(SVICP_OK)
+    // the argument is an addition: the GPU the object works on (the reference has no devices)
+    explicit CKNNSearch(int device = 0) : m_k(1), m_ctx(nullptr), m_curRows(0), m_status(SVICP_OK)
     {
-        m_status = svicp_create(0, &m_ctx);
+        m_status = svicp_create(device, &m_ctx);
     }
     virtual ~CKNNSearch()
     {

@@ -13,9 +13,10 @@
 
 class CPoint2PlaneICP {
 public:
-    CPoint2PlaneICP() : m_eps(0.f), m_count(1), m_ctx(nullptr), m_status(SVICP_OK), m_info()
+    // the argument is an addition: the GPU the object works on (the reference has no devices)
+    explicit CPoint2PlaneICP(int device = 0) : m_eps(0.f), m_count(1), m_ctx(nullptr), m_status(SVICP_OK), m_info()
     {
-        m_status = svicp_create(0, &m_ctx);
+        m_status = svicp_create(device, &m_ctx);
         for (int i = 0; i < 16; ++i) m_T[i] = (i % 5 == 0) ? 1.0 : 0.0;
     }
     ~CPoint2PlaneICP()

@@ -14,9 +14,10 @@
 
 class CPoint2PointICP {
 public:
-    CPoint2PointICP() : m_eps(0.f), m_count(1), m_ctx(nullptr), m_status(SVICP_OK), m_info()
+    // the argument is an addition: the GPU the object works on (the reference has no devices)
+    explicit CPoint2PointICP(int device = 0) : m_eps(0.f), m_count(1), m_ctx(nullptr), m_status(SVICP_OK), m_info()
     {
-        m_status = svicp_create(0, &m_ctx);
+        m_status = svicp_create(device, &m_ctx);
         for (int i = 0; i < 16; ++i) m_T[i] = (i % 5 == 0) ? 1.0 : 0.0;
     }
     ~CPoint2PointICP() { svicp_destroy(m_ctx); }
