@@ -344,7 +344,9 @@ int svicp_time_nn(svicp_ctx *ctx, int exact, int reps, double *avg_ms);
  * reports its average duration and the wave-level vector-memory instructions per run.
  * real_addresses = 1: per query the directory and probe-record look-ups and exactly the
  * candidate loads the search makes (four at a time as the search does, no distance
- * arithmetic, no result written);
+ * arithmetic, no result written); 12, 8 or 4: the same with candidate records of that
+ * many bytes (from the packed array of normals, which is sorted like the points), to
+ * see what a narrower gather would cost;
  * real_addresses = 0: per_query 16-byte loads per query from hashed places of the
  * sorted target.  The first is the floor of a per-lane gather search on this GPU for
  * this pair; the second the rate of the gather path without any locality. */

@@ -1596,7 +1596,16 @@ int svicp_time_gather(svicp_ctx *ctx, int real_addresses, int per_query, int rep
     const int grid = std::min(cdiv(n, kBlockThreads), ctx->num_cus * 8);
     unsigned long long *cnt = ctx->scr->n_unres.as<unsigned long long>();
     auto launch = [&](unsigned long long *count) {
-        if (real_addresses)
+        if (real_addresses == 12)
+            hipLaunchKernelGGL((gather_probe_kernel<true, 12>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
+                               ctx->g, x, y, z, (int)n, per_query, reinterpret_cast<unsigned *>(cnt + 1), count);
+        else if (real_addresses == 8)
+            hipLaunchKernelGGL((gather_probe_kernel<true, 8>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
+                               ctx->g, x, y, z, (int)n, per_query, reinterpret_cast<unsigned *>(cnt + 1), count);
+        else if (real_addresses == 4)
+            hipLaunchKernelGGL((gather_probe_kernel<true, 4>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
+                               ctx->g, x, y, z, (int)n, per_query, reinterpret_cast<unsigned *>(cnt + 1), count);
+        else if (real_addresses)
             hipLaunchKernelGGL((gather_probe_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
                                ctx->g, x, y, z, (int)n, per_query, reinterpret_cast<unsigned *>(cnt + 1), count);
         else

@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
 // no locality between lanes), eight in flight.  With `instr` non-null every wave adds the
 // vector-memory instructions it issued to *instr.
 // ------------------------------------------------------------------------
-template <bool REAL>
+template <bool REAL, int BYTES = 16>
 __global__ __launch_bounds__(kBlockThreads) void gather_probe_kernel(
     GridDesc g, const float *__restrict__ qx_, const float *__restrict__ qy_,
     const float *__restrict__ qz_, int n, int per_query, unsigned *__restrict__ sink,
@@ -1538,7 +1538,12 @@ __global__ __launch_bounds__(kBlockThreads) void gather_probe_kernel(
                     hsh ^= hsh >> 15; hsh *= 0x85EBCA6Bu; hsh ^= hsh >> 13;
                     j = ff < T ? hsh % (unsigned)g.m : 0u;
                 }
-                p[k] = g.pts[j];
+                // BYTES < 16: records of that size from the packed array of normals (sorted like
+                // the points, so the same neighbourhoods), to see what a narrower gather costs
+                if (BYTES == 16) p[k] = g.pts[j];
+                else if (BYTES == 12) { const Float3 t = reinterpret_cast<const Float3 *>(g.nrm)[j]; p[k] = make_float4(t.x, t.y, t.z, 0.f); }
+                else if (BYTES == 8) { const float2 t = reinterpret_cast<const float2 *>(g.nrm)[j]; p[k] = make_float4(t.x, t.y, 0.f, 0.f); }
+                else p[k] = make_float4(g.nrm[j], 0.f, 0.f, 0.f);
             }
 #pragma unroll
             // all four words are used, so that the loads stay 16-byte loads

@@ -319,7 +319,9 @@ class Context:
     def time_gather(self, real_addresses=True, per_query=16, reps=10):
         """(average ms, wave-level vector-memory instructions per run) of the gather probe."""
         ms, ins = C.c_double(), C.c_double()
-        self._check(self._lib.svicp_time_gather(self._h, 1 if real_addresses else 0, int(per_query),
+        # an integer 12, 8 or 4: the search's addresses with records of that many bytes
+        mode = real_addresses if type(real_addresses) is int else (1 if real_addresses else 0)
+        self._check(self._lib.svicp_time_gather(self._h, mode, int(per_query),
                                                 int(reps), C.byref(ms), C.byref(ins)))
         return ms.value, ins.value
 

@@ -12,6 +12,9 @@ for where in ("start", "registered"):
     real, ins = c.time_gather(True, 0, 30)
     print(f"{where}: capped 1-NN {nn:.1f} us; its loads alone {real * 1e3:.1f} us, {ins:.0f} wave instructions "
           f"({ins / (len(src) / 64):.1f} per wave of queries, {ins / real / 1e6:.1f} G/s)")
+    for nbytes in (12, 8, 4):
+        r, _ = c.time_gather(nbytes, 0, 30)
+        print(f"   the same addresses with {nbytes}-byte records: {r * 1e3:.1f} us")
     for pq in (8, 16, 24):
         r, ins2 = c.time_gather(False, pq, 30)
         print(f"   {pq} hashed loads per query: {r * 1e3:.1f} us, {ins2 / r / 1e6:.1f} G wave instructions/s")
