@@ -1,17 +1,19 @@
-"""Development probe: batched registration (64 pairs of 65536 points), device time per run."""
-import os, sys, time
+"""Development probe: device time of an arena batch for two run lengths (the difference is the settled iterations)."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import stereovision_amd as sv
 from stereovision_amd import synth
-pairs = int(os.environ.get("PAIRS", "64"))
-ctxs = []
+pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+side = 256
+tg, nr, sr = [], [], []
+t0, n0, s0, _ = synth.make_pair(side, pair=1)
+rng = np.random.default_rng(5)
 for i in range(pairs):
-    t, nrm, s, _ = synth.make_pair(256, pair=i, pose=synth.small_pose(i))
-    c = sv.Context(0); c.set_target(t, nrm); c.set_source(s); ctxs.append(c)
-b = sv.Batch(ctxs)
-for it in (30, 60):
-    b.run(it)
-    ms = []
-    for _ in range(5):
-        b.run(it); ms.append(b.last_ms())
-    print(f"{pairs} pairs, {it} iterations: {sorted(ms)[2]:.3f} ms per run, {sorted(ms)[2] / it * 1e3:.1f} us per iteration")
+    sh = rng.normal(size=3).astype(np.float32) * 0.3
+    tg.append(t0); nr.append(n0); sr.append(s0 + sh)
+b = sv.ArenaBatch(tg, nr, sr, device=0)
+for iters in (10, 30, 10, 30, 30):
+    T, infos = b.run(iters)
+    print(f"{pairs} pairs x {side * side} points, {iters} iterations: {b.last_ms():.3f} ms on the device")
+print("checksum", float(np.abs(T).sum()))
