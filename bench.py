@@ -64,6 +64,22 @@ def profile_figure(name):
     return None, None
 
 
+def profile_counters(kernel_contains, regime_contains=""):
+    """The derived counter figures (busy fractions, hit rates, wait shares) the counter passes
+    left under profiles/ for one kernel and regime; {} when there are none."""
+    path = os.path.join(ROOT, "profiles", "r02_counters.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as fh:
+        kernels = json.load(fh).get("kernels", {})
+    for name, entry in kernels.items():
+        if kernel_contains in name and regime_contains in name:
+            out = {k: v for k, v in entry.items() if k != "counters" and not isinstance(v, dict)}
+            out["source"] = "profiles/r02_counters.json"
+            return out
+    return {}
+
+
 def main():
     args = parse()
     # Libraries underneath (RCCL prints a version banner when a communicator is made) write to
@@ -548,6 +564,7 @@ def main():
                 "launches_of_this_regime_per_step": int(full.sum()),
                 "stream_copy_GBs": stream_copy_gbs, "frac_of_stream_copy": achieved_full / stream_copy_gbs,
                 "bound_in_practice": "the gather path (see roofline_correspondence.own_loads_ms), not HBM",
+                "counters": profile_counters("icp_iterate_kernel", "searches every point"),
             },
             # every launch of the timed region averaged, against the same algorithmic bytes: what
             # the figure called `roofline` was before the regimes were split
@@ -590,6 +607,8 @@ def main():
                 "note": "20 B per query + 16 B per target point; bound by the texture-address path "
                         "(one 16-byte gather per candidate per lane), not by HBM: the search runs at "
                         "frac_of_own_loads of the speed of its own loads",
+                "counters": profile_counters("nn1_kernel<false"),
+                "own_loads_counters": profile_counters("gather_probe_kernel"),
             },
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,

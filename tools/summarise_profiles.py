@@ -135,7 +135,8 @@ def regimes(pass_dirs, out, traffic_out=None):
                     pos += 1
                 elif "solve_kernel" in name and "batch" not in name and "p2p" not in name and "cal_" not in name:
                     pos = 0
-                if not (name.startswith("svicp::icp_iterate_kernel") or "nn1_kernel" in name or "cal_eval" in name):
+                if not (name.startswith("svicp::icp_iterate_kernel") or "nn1_kernel" in name or "cal_eval" in name
+                        or "gather_probe_kernel" in name):
                     continue
                 for cname, v in row.items():
                     per[(name, regime)][cname].append(v)
@@ -144,6 +145,8 @@ def regimes(pass_dirs, out, traffic_out=None):
                      "(gfx950 tallies a 128-byte read request as 64 bytes; both counters are in KB).  "
                      "ta_busy_fraction = TA_TA_BUSY_sum / (32 * GRBM_GUI_ACTIVE): the TA counter sums over "
                      "the 256 texture-address units, GRBM_GUI_ACTIVE over the 8 XCDs.  "
+                     "valu_busy_fraction = SQ_ACTIVE_INST_VALU / (32 * GRBM_GUI_ACTIVE): quad-cycles with a "
+                     "vector-ALU instruction in flight, summed over the 1024 SIMDs, over the SIMD cycles of the launch.  "
                      "l2_hit_rate = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum).  SQ_WAIT_* and "
                      "SQ_WAVE_CYCLES are in quad-cycles summed over waves.",
            "kernels": {}}
@@ -155,6 +158,8 @@ def regimes(pass_dirs, out, traffic_out=None):
             entry["hbm_bytes_per_launch"] = 2048.0 * m["FETCH_SIZE"] + 1024.0 * m["WRITE_SIZE"]
         if "TA_TA_BUSY_sum" in m and m.get("GRBM_GUI_ACTIVE"):
             entry["ta_busy_fraction"] = m["TA_TA_BUSY_sum"] / (32.0 * m["GRBM_GUI_ACTIVE"])
+        if "SQ_ACTIVE_INST_VALU" in m and m.get("GRBM_GUI_ACTIVE"):
+            entry["valu_busy_fraction"] = m["SQ_ACTIVE_INST_VALU"] / (32.0 * m["GRBM_GUI_ACTIVE"])
         if m.get("TCC_HIT_sum") is not None and (m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0)) > 0:
             entry["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
         if m.get("SQ_WAVE_CYCLES"):
