@@ -1490,7 +1490,9 @@ __global__ __launch_bounds__(kBlockThreads) void gather_probe_kernel(
     unsigned long long issued = 0;      // wave-level count (uniform)
     for (long long c = first; c < last; ++c) {
         const long long i = c * kBlockThreads + threadIdx.x;
-        const bool live = i < n;
+        // REAL with per_query = s > 1: only every s-th lane takes part (what a gather costs
+        // per active lane rather than per instruction)
+        const bool live = i < n && (!REAL || per_query <= 1 || (threadIdx.x % per_query) == 0);
         const long long ic = live ? i : 0;
         const float qx = qx_[ic], qy = qy_[ic], qz = qz_[ic];
         issued += 3;

@@ -12,6 +12,9 @@ for where in ("start", "registered"):
     real, ins = c.time_gather(True, 0, 30)
     print(f"{where}: capped 1-NN {nn:.1f} us; its loads alone {real * 1e3:.1f} us, {ins:.0f} wave instructions "
           f"({ins / (len(src) / 64):.1f} per wave of queries, {ins / real / 1e6:.1f} G/s)")
+    for stride in (2, 4, 8):
+        r, ins2 = c.time_gather(True, stride, 30)
+        print(f"   every {stride}th lane only: {r * 1e3:.1f} us, {ins2:.0f} wave instructions")
     for nbytes in (12, 8, 4):
         r, _ = c.time_gather(nbytes, 0, 30)
         print(f"   the same addresses with {nbytes}-byte records: {r * 1e3:.1f} us")
