@@ -348,12 +348,13 @@ def main():
             eval_ms = eng.ev.time_eval(reps)      # HIP events around back-to-back evaluations
         C = cl.shape[1]
         cal_bytes = 56.0 * V * C + 48.0 * V
-        # fp64 operations per (view, corner, camera), five distortion terms, as the kernel is
-        # written: 13 geometric stages (12 multiply-adds of the 3 x 4 product, two divisions,
-        # r: 26 operations), 31 pixel stages (distortion polynomial, tangential terms,
-        # intrinsics: 36), 30 central differences (a subtraction and a division each), the
+        # fp64 operations per (view, corner, camera), five distortion terms, the least the
+        # central differences need: 13 geometric stages (12 multiply-adds of the 3 x 4 product,
+        # two quotients, r: 26 operations), 31 pixel stages (distortion polynomial, tangential
+        # terms, intrinsics: 36), 30 central differences (a subtraction and a quotient each), the
         # residual, and two rank-1 updates of the 16 x 16 Gram matrix on the matrix cores
-        # (512 each); an operation is one add, multiply or divide
+        # (512 each); an operation is one add, multiply or divide.  (The kernel deals one
+        # component of a corner's rows to a lane and spends 32 stages of each kind.)
         flops_unit = 13 * 26 + 31 * 36 + 30 * 2 + 2 + 2 * 512
         flops_eval = flops_unit * 2.0 * V * C
         tf = flops_eval / (eval_ms * 1e-3) / 1e12
@@ -369,9 +370,9 @@ def main():
                 "bound": "fp64 vector", "kernel": "cal_eval_kernel<5> + cal_reduce_kernel",
                 "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TF,
                 "flops_per_view_corner_camera": flops_unit, "units": 2 * V * C,
-                "note": "56 of those operations per unit are IEEE divisions (about 20 issue slots each), "
-                        "so the issue-slot fraction is about twice the flop fraction; HBM is not the "
-                        "bound (algorithmic_GBs)",
+                "note": "the loop issues 156 vector instructions (126 fp64) and 2 matrix instructions per "
+                        "four corners at 6.6 SIMD cycles per wave instruction, whatever the occupancy; "
+                        "HBM is not the bound (algorithmic_GBs)",
                 "peak_source": "half the fp32 vector peak (157.3 TF) of MI355X_MICROARCH.md",
             },
         }

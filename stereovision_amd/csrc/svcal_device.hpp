@@ -14,9 +14,10 @@
 
 namespace svcal {
 
-constexpr int kThreads = 128;
+constexpr int kThreads = 256;      // cal_eval_kernel: four waves per view
 constexpr int kGram = 136;          // upper triangle of a 16 x 16 matrix
 constexpr double kEps = 1.0e-6;     // CStereoCameraCalibration.cpp:84
+constexpr double kInv2Eps = 1.0 / (2.0 * kEps);
 
 // Common/Misc.hpp:16-32
 __device__ inline void rodrigues(const double r[3], double R[9])
@@ -54,13 +55,27 @@ __device__ inline void ext_from(const double p[6], double *E)
 // CStereoCameraCalibration.cpp:25-50; intr = {fx, fy, cx, cy}, skew 0.
 // The projection in two stages, so that perturbations of the intrinsic parameters reuse the
 // geometry: the same operations on the same inputs as value(), hence the same bits.
+//
+// The two quotients c0 / c2, c1 / c2 of the reference (:31-32) are formed as products with
+// one reciprocal of the depth, the hardware's estimate refined twice (a relative error of a
+// few 2^-53 instead of half of one): an IEEE division is about twenty issue slots on this
+// GPU and the evaluation is bound by instruction issue, and thirteen geometric stages per
+// corner and camera carried two of them each.
+__device__ __forceinline__ double reciprocal(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return fma(r, fma(-x, r, 1.0), r);
+}
+
 __device__ __forceinline__ void project_geom(const double *E, double wx, double wy, double &nx,
                                              double &ny, double &r)
 {
     double c0 = E[0] * wx + E[1] * wy + E[2] * 0.0 + E[3] * 1.0;
     double c1 = E[4] * wx + E[5] * wy + E[6] * 0.0 + E[7] * 1.0;
     double c2 = E[8] * wx + E[9] * wy + E[10] * 0.0 + E[11] * 1.0;
-    nx = c0 / c2; ny = c1 / c2;
+    const double rc = reciprocal(c2);
+    nx = c0 * rc; ny = c1 * rc;
     r = nx * nx + ny * ny;
 }
 
@@ -82,67 +97,26 @@ __device__ __forceinline__ void project_pix(const double intr[4], const double d
     v = intr[1] * ye + intr[3];
 }
 
-// One camera's two rows of [J | e] for one corner: columns 0..nI-1 intrinsics and
-// distortion, nI..nI+5 the six pose-like parameters whose +/- eps matrices are
-// Evar[1 + 2q], Evar[2 + 2q]; the residual (projected - observed) in slot 15.
-// Central differences with eps = 1e-6 exactly as the reference forms them
-// (CStereoCameraCalibration.cpp:101-108, :122-123).
-template <int K>
-__device__ __forceinline__ void rows_for(const double *ip /* nI values */, const double *Evar,
-                                         double wx, double wy, double ox, double oy,
-                                         double (&u0)[16], double (&u1)[16])
-{
-    constexpr int nI = 4 + K;
-    const double intr[4] = { ip[0], ip[1], ip[2], ip[3] };
-    const double dist[5] = { ip[4], ip[5], K == 5 ? ip[6] : 0.0, K == 5 ? ip[7] : 0.0,
-                             K == 5 ? ip[8] : 0.0 };
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { u0[q] = 0.0; u1[q] = 0.0; }
-    double nx, ny, r, a, b, c, d;
-    project_geom(Evar, wx, wy, nx, ny, r);
-    project_pix<K>(intr, dist, nx, ny, r, a, b);
-    u0[15] = a - ox; u1[15] = b - oy;
-#pragma unroll
-    for (int col = 0; col < 4; ++col) {
-        double iu[4] = { intr[0], intr[1], intr[2], intr[3] }, il[4] = { intr[0], intr[1], intr[2], intr[3] };
-        iu[col] += kEps; il[col] -= kEps;
-        project_pix<K>(iu, dist, nx, ny, r, a, b);
-        project_pix<K>(il, dist, nx, ny, r, c, d);
-        u0[col] = (a - c) / (2.0 * kEps);
-        u1[col] = (b - d) / (2.0 * kEps);
-    }
-#pragma unroll
-    for (int col = 0; col < K; ++col) {
-        double du[5] = { dist[0], dist[1], dist[2], dist[3], dist[4] }, dl[5] = { dist[0], dist[1], dist[2], dist[3], dist[4] };
-        du[col] += kEps; dl[col] -= kEps;
-        project_pix<K>(intr, du, nx, ny, r, a, b);
-        project_pix<K>(intr, dl, nx, ny, r, c, d);
-        u0[4 + col] = (a - c) / (2.0 * kEps);
-        u1[4 + col] = (b - d) / (2.0 * kEps);
-    }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        project_geom(Evar + 12 * (1 + 2 * q), wx, wy, nx, ny, r);
-        project_pix<K>(intr, dist, nx, ny, r, a, b);
-        project_geom(Evar + 12 * (2 + 2 * q), wx, wy, nx, ny, r);
-        project_pix<K>(intr, dist, nx, ny, r, c, d);
-        u0[nI + q] = (a - c) / (2.0 * kEps);
-        u1[nI + q] = (b - d) / (2.0 * kEps);
-    }
-}
-
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int kStageStride = 17;    // doubles per staged 16-vector (one of padding: no bank conflicts)
 
-// One block per view, one wave per camera.  A lane takes a corner, builds its two
-// 16-vectors u = [J row, 0.., e] in registers, and the wave adds u u^T to its 16 x 16
-// Gram matrix with the fp64 matrix instruction (16 x 16 x 4 per step: four corners'
-// vectors at a time, staged through LDS because the instruction wants component i of
-// corner k in lane 16 k + i).  params: the parameter vector; gram_view: V x 2 x 136
-// (upper triangles, left and right camera) per view; residual: 4 V C (stereo order) or
-// 2 V C (monocular, sign flipped), may be null.
+// One block per view, four waves: camera x half of the view's corners.  The wave adds
+// u u^T, u = [J row (nI + 6 columns, zero padded to 15), e], of its corners' two rows to a
+// 16 x 16 Gram matrix with the fp64 matrix instruction (16 x 16 x 4: four corners per step).
+// The instruction wants component i of corner k in lane 16 k + i, and that is how the work is
+// dealt: a lane computes ONE component of one corner's rows, i.e. one central difference
+// (CStereoCameraCalibration.cpp:101-108, :122-123: value() at the parameter plus and minus
+// eps = 1e-6, quotient by 2 eps -- a product with 1 / (2 eps) here, one more rounding of
+// 2^-53) or, for component 15, the residual (projected - observed).  Columns 0..nI-1 perturb
+// an intrinsic or distortion parameter, nI..nI+5 project with the +/- eps variants of the
+// extrinsic matrices the first lanes have put in LDS.  Every lane runs the same two
+// projections on its own numbers: no staging through LDS, no arrays in registers (the
+// corner-per-lane version held both rows of a corner, 64 registers, unrolled over 31
+// projections: 398 registers, one wave per SIMD), and the 16 lanes of a corner share its
+// loads.  params: the parameter vector; gram_view: V x 2 x 136 (upper triangles, left and
+// right camera) per view; residual: 4 V C (stereo order) or 2 V C (monocular, sign flipped),
+// may be null.
 template <int K>
-__global__ __launch_bounds__(kThreads) void cal_eval_kernel(
+__global__ __launch_bounds__(kThreads, 4) void cal_eval_kernel(
     const double *__restrict__ params, int V, int C, int stereo,
     const double *__restrict__ world_xy, const double *__restrict__ left_xy,
     const double *__restrict__ right_xy, double *__restrict__ gram_view,
@@ -150,9 +124,9 @@ __global__ __launch_bounds__(kThreads) void cal_eval_kernel(
 {
     constexpr int nI = 4 + K;
     __shared__ double ext[2][13 * 12];                       // [camera][variant][3x4]
-    __shared__ double stage[2][64 * kStageStride];           // [wave][corner][16 + 1]
+    __shared__ v4d part[2][64];                              // the second half's sums, per camera
     const int view = blockIdx.x;
-    const int t = threadIdx.x, lane = t & 63, cam = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, cam = wave & 1, split = wave >> 1;
     const double *pE = params + (stereo ? 2 * nI : nI) + 6 * view;
     const double *pS = params + 2 * nI + 6 * V;
 
@@ -163,12 +137,18 @@ __global__ __launch_bounds__(kThreads) void cal_eval_kernel(
         if (t > 0) p[(t - 1) >> 1] += ((t - 1) & 1) ? -kEps : kEps;
         ext_from(p, &ext[0][12 * t]);
     }
-    __syncthreads();
-    if (stereo && cam == 1 && lane < 13) {
-        double p[6], S[12];
+    // (the second wave forms the pose's variants meanwhile: two Rodrigues formulas one after
+    // the other were a sixth of the kernel)
+    const bool right_lane = stereo && wave == 1 && lane < 13;
+    double S[12];
+    if (right_lane) {
+        double p[6];
         for (int q = 0; q < 6; ++q) p[q] = pS[q];
         if (lane > 0) p[(lane - 1) >> 1] += ((lane - 1) & 1) ? -kEps : kEps;
         ext_from(p, S);
+    }
+    __syncthreads();
+    if (right_lane) {
         // pose * [left extrinsic; 0 0 0 1]  (CStereoCameraCalibration.cpp:573-579)
         const double *L = &ext[0][0];
         for (int r = 0; r < 3; ++r)
@@ -180,47 +160,72 @@ __global__ __launch_bounds__(kThreads) void cal_eval_kernel(
             }
     }
     __syncthreads();
-    if (cam == 1 && !stereo) return;                         // (whole wave)
+    const bool active = cam == 0 || stereo;                  // (whole wave)
+
+    const int comp = lane & 15, k = lane >> 4;               // component of u, corner of the step
+    const bool resid = comp == 15;
+    const bool pose_col = comp >= nI && comp < nI + 6;
+    const bool padding = !resid && comp >= nI + 6;           // (K = 2 only)
+    const int vp = pose_col ? 1 + 2 * (comp - nI) : 0, vm = pose_col ? 2 + 2 * (comp - nI) : 0;
+    const double *Ep = &ext[cam][12 * vp], *Em = &ext[cam][12 * vm];
+    const double *ip = params + cam * nI;
+    // the lane's parameter sets: its own parameter plus and minus eps, the others as they are
+    double intr_p[4], intr_m[4], dist_p[5], dist_m[5];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double v = ip[c];
+        intr_p[c] = comp == c ? v + kEps : v;
+        intr_m[c] = comp == c ? v - kEps : v;
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const double v = c < K ? ip[4 + c] : 0.0;
+        dist_p[c] = (c < K && comp == 4 + c) ? v + kEps : v;
+        dist_m[c] = (c < K && comp == 4 + c) ? v - kEps : v;
+    }
 
     const double *obs = cam == 0 ? left_xy : right_xy;
-    const double *ip = params + cam * nI;
-    double *st = stage[cam];
+    // the first half of the corners (a multiple of four) to split 0, the rest to split 1
+    const int first_half = ((C + 7) / 8) * 4;
+    const int j_begin = split == 0 ? 0 : (first_half < C ? first_half : C);
+    const int j_end = split == 0 ? (first_half < C ? first_half : C) : C;
     v4d acc = { 0.0, 0.0, 0.0, 0.0 };
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        const int j = c0 + lane;
-        double u0[16], u1[16];
-        if (j < C) {
-            const double wx = world_xy[2 * j], wy = world_xy[2 * j + 1];
-            const size_t o = 2 * ((size_t)view * C + j);
-            rows_for<K>(ip, &ext[cam][0], wx, wy, obs[o], obs[o + 1], u0, u1);
-            if (residual) {
+    if (active) {
+        for (int jb = j_begin; jb < j_end; jb += 4) {
+            const int j = jb + k;
+            const bool valid = j < j_end;
+            const int jc = valid ? j : j_begin;
+            const double wx = world_xy[2 * jc], wy = world_xy[2 * jc + 1];
+            const size_t o = 2 * ((size_t)view * C + jc);
+            const double ox = obs[o], oy = obs[o + 1];
+            double nx, ny, r, a, b, c, d;
+            project_geom(Ep, wx, wy, nx, ny, r);
+            project_pix<K>(intr_p, dist_p, nx, ny, r, a, b);
+            project_geom(Em, wx, wy, nx, ny, r);
+            project_pix<K>(intr_m, dist_m, nx, ny, r, c, d);
+            double u0 = resid ? a - ox : (a - c) * kInv2Eps;
+            double u1 = resid ? b - oy : (b - d) * kInv2Eps;
+            if (padding || !valid) { u0 = 0.0; u1 = 0.0; }
+            if (residual && resid && valid) {
                 if (stereo) {
-                    residual[(size_t)cam * 2 * V * C + o] = u0[15];
-                    residual[(size_t)cam * 2 * V * C + o + 1] = u1[15];
+                    residual[(size_t)cam * 2 * V * C + o] = u0;
+                    residual[(size_t)cam * 2 * V * C + o + 1] = u1;
                 } else {
-                    residual[o] = -u0[15];
-                    residual[o + 1] = -u1[15];
+                    residual[o] = -u0;
+                    residual[o + 1] = -u1;
                 }
             }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { u0[q] = 0.0; u1[q] = 0.0; }
+            // A[row = lane & 15][k = lane >> 4] and B[k][col = lane & 15] are the same number
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, u0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, u1, acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) st[lane * kStageStride + q] = half ? u1[q] : u0[q];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                // A[row = lane & 15][k = lane >> 4] and B[k][col = lane & 15] are the same number
-                const double a = st[(4 * kk + (lane >> 4)) * kStageStride + (lane & 15)];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-        }
+    }
+    if (split == 1) part[cam][lane] = acc;
+    __syncthreads();
+    if (split == 1 || !active) return;
+    {
+        const v4d other = part[cam][lane];
+        acc += other;
     }
     // result (row = (lane >> 4) + 4 reg, col = lane & 15); keep the upper triangle
     double *out = gram_view + ((size_t)view * 2 + cam) * kGram;

@@ -1,7 +1,8 @@
 """Development harness: times the calibration evaluation at the 2000-view size."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stereovision_amd import synth
 from stereovision_amd.calib import ReprojectionEvaluator
 
