@@ -2,7 +2,7 @@
 """Benchmark of the point-to-plane ICP hot path on MI355X.
 
 A step is one registration of a synthetic 1024^2-point pair with analytic
-normals, 30 iterations, clouds resident in HBM (BASELINE.json configs[1]).
+normals, 30 iterations, clouds resident in HBM (the headline configuration, configs[1]).
 With N > 1 ranks every rank registers its own independent pair (no data-path
 collective) and `value` is the aggregate iterations/s.  The same run also
 times, at every N through the same code path:
@@ -596,7 +596,7 @@ def main():
                 "launches_of_this_regime_per_step": int(settled.sum()),
                 "where_the_time_goes_us": {"kernel boundary": 2.7, "redundant solve": 1.6,
                                            "tiles that still have work": 3.5,
-                                           "source": "per-block stamps of a trace build (DESIGN.md section 6)"},
+                                           "source": "per-block wall-clock stamps of a build with -DSVICP_TRACE (tools/trace_probe.py)"},
             },
             # the standalone correspondence kernel (the reduction has no kernel of its own: it is
             # fused into icp_iterate_kernel)
