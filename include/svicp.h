@@ -51,6 +51,12 @@ typedef struct svicp_options {
                               correspondence is provably still its nearest neighbour
                               skips the search (same result, bit for bit); 0: search
                               every point in every iteration                          */
+    int centred_normals;   /* 0 (the reference): second moments about the ORIGIN, each
+                              term rounded to fp32 and divided by k in fp32
+                              (CPoint2PlaneICP.cpp:140-146); 1: the covariance about the
+                              neighbourhood's centroid, in fp64 -- the textbook estimate,
+                              which the reference's is not once a cloud is far from the
+                              origin                                                   */
 } svicp_options;
 
 /* Per-run summary.  Arrays hold the LAST iteration's figures. */

@@ -26,6 +26,7 @@ class Options(C.Structure):
         ("time_kernels", C.c_int),
         ("sort_source", C.c_int),
         ("coherent", C.c_int),
+        ("centred_normals", C.c_int),
     ]
 
 

@@ -674,6 +674,7 @@ int svicp_default_options(svicp_options *opt)
     opt->time_kernels = 0;
     opt->sort_source = 1;
     opt->coherent = 1;
+    opt->centred_normals = 0;
     return SVICP_OK;
 }
 
@@ -944,7 +945,7 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
             if (rc) return rc;
             hipLaunchKernelGGL(normals_kernel, dim3(cdiv(m, kBlockThreads)), dim3(kBlockThreads), 0,
                                ctx->stream, ctx->scr->tgt_aos.as<float>(), ctx->scr->knn_idx.as<int>(), (int)m,
-                               k, ctx->scr->nrm_aos.as<float>());
+                               k, ctx->opt.centred_normals != 0, ctx->scr->nrm_aos.as<float>());
             LAUNCHCHK("normals_kernel");
         }
         hipLaunchKernelGGL(gather_target_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream,

@@ -1994,16 +1994,26 @@ __global__ __launch_bounds__(kBlockThreads) void knn_brute_block_kernel(
 // fp64 in neighbour order, eigenvector of the smallest eigenvalue (cyclic
 // Jacobi on the 3x3), stored as fp32.  The sign of a normal is not defined by
 // the reference's eigen-solver and does not affect the registration.
+// centred (an option the reference does not have): the covariance of the neighbourhood about
+// its centroid, in fp64, instead of the moments about the origin.
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlockThreads) void normals_kernel(const float *__restrict__ ref_aos,
                                                                 const int *__restrict__ knn_idx,
-                                                                int m, int k,
+                                                                int m, int k, bool centred,
                                                                 float *__restrict__ normals)
 {
     const long long p = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
     if (p >= m) return;
     double W[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+    double mean[3] = { 0, 0, 0 };
     const float kf = (float)k;
+    if (centred) {
+        for (int t = 0; t < k; ++t) {
+            const size_t at = 3 * (size_t)knn_idx[p * k + t];
+            mean[0] += (double)ref_aos[at]; mean[1] += (double)ref_aos[at + 1]; mean[2] += (double)ref_aos[at + 2];
+        }
+        mean[0] /= (double)k; mean[1] /= (double)k; mean[2] /= (double)k;
+    }
     // four neighbours at a time: their indices, then their coordinates, are asked for together
     // (one after the other, each neighbour costs two round trips to memory); the sums still
     // take the terms in neighbour order
@@ -2020,6 +2030,15 @@ __global__ __launch_bounds__(kBlockThreads) void normals_kernel(const float *__r
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (id[u] < 0) continue;
+            if (centred) {
+                const double d[3] = { (double)c[u][0] - mean[0], (double)c[u][1] - mean[1],
+                                      (double)c[u][2] - mean[2] };
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) W[j][i] += d[j] * d[i];
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll

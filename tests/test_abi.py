@@ -50,12 +50,12 @@ def test_calibration_needs_a_device():
 
 def test_struct_layouts_match_header():
     from stereovision_amd import _lib
-    assert ctypes.sizeof(_lib.Options) == 24
+    assert ctypes.sizeof(_lib.Options) == 28
     assert ctypes.sizeof(_lib.Info) == 40
     o = _lib.Options()
     assert _lib.load().svicp_default_options(ctypes.byref(o)) == 0
     assert o.dist_threshold == 5.0 and o.normals_k == 20        # CPoint2PlaneICP.cpp:68,125
-    assert o.use_graph == 1 and o.sort_source == 1 and o.coherent == 1
+    assert o.use_graph == 1 and o.sort_source == 1 and o.coherent == 1 and o.centred_normals == 0
 
 
 def test_no_device_is_an_error_not_a_fallback():

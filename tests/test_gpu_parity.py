@@ -34,6 +34,36 @@ def test_normals_match_oracle(ctx, pair):
     assert (np.abs((n * gold["normals"]).sum(1)) > 0.999999).all()
 
 
+def test_centred_normals_option_is_the_covariance_estimate(ctx, pair, po):
+    """centred_normals = 1 has no counterpart in the reference (CPoint2PlaneICP.cpp:140-146 sums
+    moments about the origin): checked against numpy's eigenvectors of the 20-neighbourhood
+    covariance, and on a synthetic surface against the analytic normals, where the reference's
+    estimate is visibly the worse one."""
+    from stereovision_amd import synth
+    ref, _, gold = pair
+    ctx.set_options(centred_normals=1)
+    try:
+        ctx.set_target(ref)
+        n = ctx.get_normals()
+        idx, _ = po.KDTree(ref).knn(ref, 20)
+        nb = ref[idx].astype(np.float64)                        # m x 20 x 3
+        d = nb - nb.mean(1, keepdims=True)
+        w, v = np.linalg.eigh(np.einsum("mki,mkj->mij", d, d))
+        want = v[:, :, 0]
+        clear = (w[:, 1] - w[:, 0]) > 1e-3 * w[:, 2]            # smallest eigenvalue well separated
+        cosines = np.abs((n * want).sum(1))
+        assert clear.mean() > 0.95 and (cosines[clear] > 1 - 1e-6).all()
+        tgt, nrm, _, _ = synth.make_pair(256)
+        ctx.set_target(tgt)
+        centred = np.abs((ctx.get_normals() * nrm).sum(1))
+        ctx.set_options(centred_normals=0)
+        ctx.set_target(tgt)
+        as_reference = np.abs((ctx.get_normals() * nrm).sum(1))
+        assert np.median(centred) > 0.995 and np.median(centred) > np.median(as_reference)
+    finally:
+        ctx.set_options(centred_normals=0)
+
+
 def test_knn_bit_exact_on_bundled_pair(ctx, pair, po):
     ref, src, gold = pair
     ctx.set_target(ref, gold["normals"])
