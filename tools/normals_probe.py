@@ -1,4 +1,6 @@
-import sys; sys.path.insert(0,'.')
+"""Development probe: estimated normals of the synthetic surface against its analytic ones, both modes."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, stereovision_amd as sv
 from stereovision_amd import synth
 tgt, nrm, _, _ = synth.make_pair(256)
