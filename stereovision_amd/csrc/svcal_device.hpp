@@ -29,7 +29,9 @@ __device__ inline void rodrigues(const double r[3], double R[9])
     }
     double a0 = r[0] / theta, a1 = r[1] / theta, a2 = r[2] / theta;
     double K[9] = { 0, -a2, a1, a2, 0, -a0, -a1, a0, 0 };
-    double sn = sin(theta), cs = 1.0 - cos(theta);
+    double sn, cs;
+    sincos(theta, &sn, &cs);        // (one range reduction for both)
+    cs = 1.0 - cs;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
