@@ -127,6 +127,7 @@ __global__ __launch_bounds__(kThreads, 4) void cal_eval_kernel(
     constexpr int nI = 4 + K;
     __shared__ double ext[2][13 * 12];                       // [camera][variant][3x4]
     __shared__ v4d part[2][64];                              // the second half's sums, per camera
+    __shared__ double geo[kThreads / 64][4][13][3];          // [wave][corner of the step][variant]{nx, ny, r}
     const int view = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, cam = wave & 1, split = wave >> 1;
     const double *pE = params + (stereo ? 2 * nI : nI) + 6 * view;
@@ -169,7 +170,13 @@ __global__ __launch_bounds__(kThreads, 4) void cal_eval_kernel(
     const bool pose_col = comp >= nI && comp < nI + 6;
     const bool padding = !resid && comp >= nI + 6;           // (K = 2 only)
     const int vp = pose_col ? 1 + 2 * (comp - nI) : 0, vm = pose_col ? 2 + 2 * (comp - nI) : 0;
-    const double *Ep = &ext[cam][12 * vp], *Em = &ext[cam][12 * vm];
+    // the geometric stage of a step is dealt differently: lane 13 c + g (52 of the 64) projects
+    // corner c of the step with variant g of the extrinsic matrix, once, and the components
+    // fetch the two results they difference from LDS (dealt by component, every lane would
+    // run two geometric stages: 32 per corner where 13 are different)
+    const int gc = lane / 13, gv = lane - 13 * gc;           // (gc = 4: no geometric work)
+    const double *Eg = &ext[cam][12 * (gc < 4 ? gv : 0)];
+    double (*const mygeo)[13][3] = geo[wave];
     const double *ip = params + cam * nI;
     // the lane's parameter sets: its own parameter plus and minus eps, the others as they are
     double intr_p[4], intr_m[4], dist_p[5], dist_m[5];
@@ -197,14 +204,20 @@ __global__ __launch_bounds__(kThreads, 4) void cal_eval_kernel(
             const int j = jb + k;
             const bool valid = j < j_end;
             const int jc = valid ? j : j_begin;
-            const double wx = world_xy[2 * jc], wy = world_xy[2 * jc + 1];
             const size_t o = 2 * ((size_t)view * C + jc);
             const double ox = obs[o], oy = obs[o + 1];
             double nx, ny, r, a, b, c, d;
-            project_geom(Ep, wx, wy, nx, ny, r);
-            project_pix<K>(intr_p, dist_p, nx, ny, r, a, b);
-            project_geom(Em, wx, wy, nx, ny, r);
-            project_pix<K>(intr_m, dist_m, nx, ny, r, c, d);
+            if (gc < 4) {
+                const int jg = jb + gc < j_end ? jb + gc : j_begin;
+                project_geom(Eg, world_xy[2 * jg], world_xy[2 * jg + 1], nx, ny, r);
+                mygeo[gc][gv][0] = nx; mygeo[gc][gv][1] = ny; mygeo[gc][gv][2] = r;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            project_pix<K>(intr_p, dist_p, mygeo[k][vp][0], mygeo[k][vp][1], mygeo[k][vp][2], a, b);
+            project_pix<K>(intr_m, dist_m, mygeo[k][vm][0], mygeo[k][vm][1], mygeo[k][vm][2], c, d);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
             double u0 = resid ? a - ox : (a - c) * kInv2Eps;
             double u1 = resid ? b - oy : (b - d) * kInv2Eps;
             if (padding || !valid) { u0 = 0.0; u1 = 0.0; }
