@@ -376,7 +376,7 @@ def main():
                 "bound": "fp64 vector", "kernel": "cal_eval_kernel<5> + cal_reduce_kernel",
                 "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TF,
                 "flops_per_view_corner_camera": flops_unit, "units": 2 * V * C,
-                "note": "the loop issues 156 vector instructions (126 fp64) and 2 matrix instructions per "
+                "note": "the loop issues 124 vector instructions (102 fp64) and 2 matrix instructions per "
                         "four corners at 6.6 SIMD cycles per wave instruction, whatever the occupancy; "
                         "HBM is not the bound (algorithmic_GBs)",
                 "peak_source": "half the fp32 vector peak (157.3 TF) of MI355X_MICROARCH.md",
