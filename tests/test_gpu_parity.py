@@ -64,6 +64,33 @@ def test_centred_normals_option_is_the_covariance_estimate(ctx, pair, po):
         ctx.set_options(centred_normals=0)
 
 
+def test_non_finite_coordinates(ctx):
+    """The reference validates nothing (NaNs would wander through FLANN and Eigen).  Here an
+    infinite coordinate is refused, and a NaN point is inert: a NaN source point finds no
+    neighbour, a NaN target point is nobody's neighbour, the other points register as before."""
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+    tgt, nrm, src, _ = synth.make_pair(48)
+    ctx.set_target(tgt, nrm)
+    ctx.set_source(src)
+    T0, info0 = ctx.run(8)
+    bad = tgt.copy()
+    bad[5, 1] = np.inf
+    with pytest.raises(sv.SvicpError):
+        ctx.set_target(bad, nrm)
+    t2, s2 = tgt.copy(), src.copy()
+    t2[[7, 100, 2000], :] = np.nan
+    s2[[3, 50, 1500], 0] = np.nan
+    ctx.set_target(t2, nrm)
+    ctx.set_source(s2)
+    T1, info1 = ctx.run(8)
+    assert info1.status == 0 and abs(info1.inliers - info0.inliers) <= 12
+    assert np.abs(T1 - T0).max() < 0.05
+    idx, d2 = ctx.correspondences()
+    assert (idx[[3, 50, 1500]] == -1).all() and np.isinf(d2[[3, 50, 1500]]).all()
+    assert not np.isin(idx, [7, 100, 2000]).any()
+
+
 def test_knn_bit_exact_on_bundled_pair(ctx, pair, po):
     ref, src, gold = pair
     ctx.set_target(ref, gold["normals"])
