@@ -91,6 +91,38 @@ def test_non_finite_coordinates(ctx):
     assert not np.isin(idx, [7, 100, 2000]).any()
 
 
+def test_contexts_on_several_host_threads():
+    """One object per thread at a time, objects independent (as the reference's classes): four
+    threads making, using and destroying their own contexts at once get the serial results."""
+    import threading
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+    pairs = [synth.make_pair(64 + 16 * i, pair=i) for i in range(4)]
+
+    def register(i):
+        tgt, nrm, src, _ = pairs[i]
+        with sv.Context(0) as c:
+            c.set_target(tgt, nrm)
+            c.set_source(src)
+            T = c.run(10)[0]
+            c.knn(src[:100], 5)
+            return T
+
+    serial = [register(i) for i in range(4)]
+    out = [[] for _ in range(4)]
+
+    def work(i):
+        for _ in range(6):
+            out[i].append(register(i))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(len(out[i]) == 6 and all(np.array_equal(T, serial[i]) for T in out[i]) for i in range(4))
+
+
 def test_knn_bit_exact_on_bundled_pair(ctx, pair, po):
     ref, src, gold = pair
     ctx.set_target(ref, gold["normals"])
