@@ -169,3 +169,28 @@ def test_shard_run_with_one_rank_communicator_equals_run(po):
         ctx.comm_destroy()
         r = po.icp_point2plane(po.KDTree(tgt), nrm, src, 8)
         assert np.abs(T1 - r["trans"]).max() < 1e-8
+
+
+def test_config3_pair_registers_through_shard_run():
+    """The 16.8 M-point pair of the sharded configuration (16 384 tiles: the flag rows are out of
+    use and the solve has a launch of its own), 30 iterations through svicp_shard_run with a
+    one-rank communicator: it must arrive at its generating pose, with nearly every point
+    matched, and a second run must give the same bits."""
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+    from stereovision_amd.sharded import init_comm, run_sharded_native
+    tgt, nrm, src, P = synth.make_pair(4096, inlier_frac=0.7)
+    with sv.Context(0) as ctx:
+        ctx.set_target(tgt, nrm)
+        ctx.set_source(src)
+        init_comm(ctx)
+        T, info = run_sharded_native(ctx, 30)
+        assert info.status == 0 and info.iterations == 30
+        assert np.abs(T @ P - np.eye(4)).max() < 5e-4
+        assert info.inliers > 0.98 * len(src)
+        counts = ctx.search_counts()
+        assert counts[0] == len(src) and counts[-1] < 1000
+        ctx.set_source(src)
+        T2, info2 = run_sharded_native(ctx, 30)
+        assert np.array_equal(T, T2) and info2.inliers == info.inliers
+        ctx.comm_destroy()
