@@ -91,6 +91,18 @@ int svcal_set_update_intrinsics(svcal_ctx *ctx, int update_intrinsics);
 /* |e|^2 of the last svcal_eval alone (two doubles come back instead of every block). */
 int svcal_sq_residual(svcal_ctx *ctx, double *out);
 
+/* The refinement loop itself (CStereoCameraCalibration.cpp:278-335, the same in
+ * CMonocularCameraCalibration::refineAllPara): lambda starts at 1e-3; per iteration the damped
+ * step (svcal_solve_damped), one evaluation at the trial parameters, the gain ratio
+ * r = (|e|^2 - |e'|^2) / (step^T (lambda step - G)) (:312-313); r > 0: the step is taken and
+ * lambda *= max(1/3, 1 - (2 r - 1)^3) (:325), else lambda *= v, v *= 2 (:330-331); stops when
+ * |step| < 1e-5 (:293), |e| < 1e-3 (:323) or after max_iterations (100 in the reference, :282).
+ * params (the parameter vector as svcal_set_params takes it) is refined in place;
+ * iterations_out / rms_out (either may be NULL): iterations performed and the final |e|.
+ * Only the step and |e|^2 cross to the host per iteration; the blocks stay on the device. */
+int svcal_lm_refine(svcal_ctx *ctx, double *params, int k_size, int max_iterations,
+                    int *iterations_out, double *rms_out);
+
 /* Runs the context's work on the caller's HIP stream (use_own = 0; NULL is the
  * default stream) or back on the context's own stream (use_own = 1). */
 int svcal_set_stream(svcal_ctx *ctx, void *hip_stream, int use_own);

@@ -36,6 +36,7 @@ CAL_SYMBOLS = {
     "svcal_eval": (C.c_int, [C.c_void_p]),
     "svcal_fetch": (C.c_int, [C.c_void_p, C.POINTER(_Blocks)]),
     "svcal_sq_residual": (C.c_int, [C.c_void_p, _dp]),
+    "svcal_lm_refine": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, C.POINTER(C.c_int), _dp]),
     "svcal_set_update_intrinsics": (C.c_int, [C.c_void_p, C.c_int]),
     "svcal_solve_damped": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp]),
     "svcal_solve_begin": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
@@ -137,6 +138,15 @@ class ReprojectionEvaluator:
         out = C.c_double(0.0)
         self._check(self._lib.svcal_sq_residual(self._h, C.byref(out)))
         return out.value
+
+    def lm_refine(self, params, k=5, max_iter=100):
+        """The reference's refinement loop inside the library (svcal_lm_refine): returns
+        (refined parameters, final |e|, iterations)."""
+        x = np.array(params, np.float64)
+        its, rms = C.c_int(0), C.c_double(0.0)
+        self._check(self._lib.svcal_lm_refine(self._h, _d(x), int(k), int(max_iter), C.byref(its), C.byref(rms)))
+        self.k = int(k)
+        return x, rms.value, its.value
 
     def set_update_intrinsics(self, update_intrinsics):
         """doStereoCalibrate's update_intrinsics: False freezes the 2 (4 + k) intrinsic and

@@ -389,6 +389,60 @@ int svcal_solve_damped(svcal_ctx *ctx, double lam, double *step_out, double *pre
     return SVICP_OK;
 }
 
+int svcal_lm_refine(svcal_ctx *ctx, double *params, int k_size, int max_iterations,
+                    int *iterations_out, double *rms_out)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (!params || max_iterations < 0)
+        return cfail(ctx, SVICP_ERR_ARG, "svcal_lm_refine: bad argument");
+    if (!ctx->have_obs) return cfail(ctx, SVICP_ERR_ARG, "svcal_lm_refine: set the observations first");
+    const int nI = 4 + k_size;
+    const size_t P = (size_t)(ctx->stereo ? 2 * nI + 6 : nI) + 6 * (size_t)ctx->V;
+    std::vector<double> step(P), trial(P);
+    auto evaluate = [&](const double *p, double *sq) -> int {
+        int rc = svcal_set_params(ctx, p, k_size);
+        if (rc == SVICP_OK) rc = svcal_eval(ctx);
+        if (rc == SVICP_OK) rc = svcal_sq_residual(ctx, sq);
+        return rc;
+    };
+    double err2 = 0.0;
+    int rc = evaluate(params, &err2);
+    if (rc) return rc;
+    double lam = 1.0e-3, v = 2.0;
+    int it = 0;
+    for (; it < max_iterations; ++it) {
+        double denom = 0.0;
+        rc = svcal_solve_damped(ctx, lam, step.data(), &denom);
+        if (rc) return rc;
+        double norm2 = 0.0;
+        for (size_t i = 0; i < P; ++i) norm2 += step[i] * step[i];
+        if (std::sqrt(norm2) < 1.0e-5) break;
+        for (size_t i = 0; i < P; ++i) trial[i] = params[i] + step[i];
+        double new2 = 0.0;
+        rc = evaluate(trial.data(), &new2);
+        if (rc) return rc;
+        const double r = (err2 - new2) / denom;
+        if (r > 0) {
+            std::memcpy(params, trial.data(), sizeof(double) * P);
+            err2 = new2;
+            if (std::sqrt(err2) < 1.0e-3) { ++it; break; }
+            const double c = 2.0 * r - 1.0;
+            lam *= std::max(1.0 / 3.0, 1.0 - c * c * c);
+            v = 2.0;
+        } else {
+            // the device holds the rejected trial's blocks: the loop needs the old ones back
+            double again = 0.0;
+            rc = evaluate(params, &again);
+            if (rc) return rc;
+            lam *= v;
+            v *= 2.0;
+        }
+    }
+    if (iterations_out) *iterations_out = it;
+    if (rms_out) *rms_out = std::sqrt(err2);
+    return SVICP_OK;
+}
+
 int svcal_solve_begin(svcal_ctx *ctx, double lam, double *dev_sums90)
 {
     if (!ctx || !dev_sums90) return cfail(ctx, SVICP_ERR_ARG, "svcal_solve_begin: NULL argument");

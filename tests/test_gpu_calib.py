@@ -149,6 +149,30 @@ def test_two_thousand_views_refine_to_the_noise_floor(po):
     assert np.abs(x[-3:] - truth[-3:]).max() < 0.05         # baseline, millimetres
 
 
+@pytest.mark.parametrize("views,stereo", [(2000, True), (40, True), (9, False)])
+def test_refinement_loop_inside_the_library(views, stereo):
+    """svcal_lm_refine (the reference's loop, CStereoCameraCalibration.cpp:278-335, as one C call)
+    walks the same steps as the Python loop over svcal_solve_damped."""
+    from stereovision_amd.calib import ReprojectionEvaluator, lm_refine
+    w, l, r, _, start = synth.make_stereo_views(views=views, perturb=1e-2)
+    a = ReprojectionEvaluator(w, l, r if stereo else None)
+    b = ReprojectionEvaluator(w, l, r if stereo else None)
+    start = start if stereo else np.concatenate([start[:9], start[18:18 + 6 * views]])
+    # three iterations from a perturbed start: far from convergence, the same steps
+    x_py, err_py = lm_refine(a, start, 5, max_iter=3)
+    x_c, err_c, its = b.lm_refine(start, 5, max_iter=3)
+    assert its == 3
+    assert np.abs(x_c - x_py).max() < 1e-9 * max(1.0, np.abs(x_py).max())
+    assert err_c == pytest.approx(err_py, rel=1e-9)
+    # to the end: both arrive at the noise floor (at it, which tiny steps are still accepted
+    # hangs on the last bits of the gain ratio)
+    x_py, err_py = lm_refine(a, start, 5, max_iter=30)
+    x_c, err_c, its = b.lm_refine(start, 5, max_iter=30)
+    assert 3 < its <= 30 and err_c == pytest.approx(err_py, rel=1e-6)
+    with pytest.raises(Exception):
+        b.lm_refine(start, 5, max_iter=-1)
+
+
 @pytest.mark.parametrize("views,stereo,k", [(6, True, 5), (6, True, 2), (7, False, 5), (2000, True, 5)])
 def test_device_step_equals_host_step(views, stereo, k):
     """svcal_solve_damped against the numpy block-sparse solve of the fetched blocks (and,
