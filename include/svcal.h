@@ -134,6 +134,18 @@ int svcal_solve_begin(svcal_ctx *ctx, double lam, double *dev_sums90);
 int svcal_solve_end(svcal_ctx *ctx, double lam, const double *dev_sums90, double *step_out,
                     double predicted_out[2]);
 
+/* CStereoCameraRectification::doStereoRectify (Calibration/CStereoCameraRectification.cpp:13-58):
+ * from the two intrinsic matrices and the pose of the right camera (R, T: 3 x 3 row-major
+ * and 3), the rectifying projections of both cameras (3 x 3, row-major: new intrinsics times
+ * the rectifying rotation) and the 4 x 4 reprojection matrix Q.  Half of the relative
+ * rotation goes to each camera (the rotation vector of R^-1, halved, Common/Misc.hpp:7-75; the
+ * nearest rotation to the given matrix is taken first, as the reference's SVD does), the new
+ * x axis is the baseline, the new focal length the mean of the four given ones.  Host
+ * arithmetic only, no context.  SVICP_ERR_SINGULAR when R cannot be inverted or the baseline
+ * has no x / y component to build the frame from. */
+int svcal_stereo_rectify(const double KL[9], const double KR[9], const double R[9], const double T[3],
+                         double left_proj[9], double right_proj[9], double Q[16]);
+
 /* CStereoCameraRectification::doImageRectify
  * (Calibration/CStereoCameraRectification.cpp:60-143): for every pixel (i, j) of the
  * rectified image, the position in the original left / right image to sample:

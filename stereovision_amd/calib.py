@@ -45,6 +45,7 @@ CAL_SYMBOLS = {
     "svcal_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "svcal_shard_export": (C.c_int, [C.c_void_p, C.c_void_p]),
     "svcal_shard_import": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "svcal_stereo_rectify": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "svcal_rectify_maps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp,
                                      _dp, _dp, _dp, _dp, _dp]),
 }
@@ -510,6 +511,17 @@ def lm_refine_sharded(engine, params, k, V_total, begin, end, group=None, max_it
             lam *= v
             v *= 2.0
     return x, np.sqrt(err2)
+
+
+def stereo_rectify_native(KL, KR, R, T):
+    """svcal_stereo_rectify: doStereoRectify in the library (host arithmetic; no GPU needed)."""
+    lib = _load()
+    arrs = [np.ascontiguousarray(a, np.float64).reshape(-1) for a in (KL, KR, R, T)]
+    lp, rp, Q = np.zeros(9), np.zeros(9), np.zeros(16)
+    rc = lib.svcal_stereo_rectify(*[_d(a) for a in arrs], _d(lp), _d(rp), _d(Q))
+    if rc != 0:
+        raise _lib.SvicpError(rc, "svcal_stereo_rectify")
+    return lp.reshape(3, 3), rp.reshape(3, 3), Q.reshape(4, 4)
 
 
 def stereo_rectify(KL, KR, R, T):

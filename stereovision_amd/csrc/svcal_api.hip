@@ -527,6 +527,108 @@ bool invert3(const double A[9], double out[9])
 }
 }  // namespace
 
+namespace {
+// 3 x 3 helpers of svcal_stereo_rectify (row-major)
+void mat3_mul(const double *a, const double *b, double *c)
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+bool mat3_inv(const double *a, double *inv)
+{
+    const double c0 = a[4] * a[8] - a[5] * a[7], c1 = a[5] * a[6] - a[3] * a[8], c2 = a[3] * a[7] - a[4] * a[6];
+    const double det = a[0] * c0 + a[1] * c1 + a[2] * c2;
+    if (!(std::fabs(det) > 1e-300)) return false;
+    const double d = 1.0 / det;
+    inv[0] = c0 * d; inv[1] = (a[2] * a[7] - a[1] * a[8]) * d; inv[2] = (a[1] * a[5] - a[2] * a[4]) * d;
+    inv[3] = c1 * d; inv[4] = (a[0] * a[8] - a[2] * a[6]) * d; inv[5] = (a[2] * a[3] - a[0] * a[5]) * d;
+    inv[6] = c2 * d; inv[7] = (a[1] * a[6] - a[0] * a[7]) * d; inv[8] = (a[0] * a[4] - a[1] * a[3]) * d;
+    return true;
+}
+// rotation matrix -> rotation vector (Common/Misc.hpp:36-70).  The reference first replaces
+// the matrix by U V^T of its SVD, the nearest orthogonal matrix; the same matrix is the limit
+// of X <- (X + X^-T) / 2, which gets there in a few steps from anything near a rotation.
+bool rotation_vector(const double *Rin, double *r)
+{
+    double R[9];
+    std::memcpy(R, Rin, sizeof R);
+    for (int it = 0; it < 30; ++it) {
+        double inv[9];
+        if (!mat3_inv(R, inv)) return false;
+        double change = 0.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const double x = 0.5 * (R[3 * i + j] + inv[3 * j + i]);
+                change = std::max(change, std::fabs(x - R[3 * i + j]));
+                R[3 * i + j] = x;
+            }
+        if (change < 1e-16) break;
+    }
+    r[0] = R[7] - R[5]; r[1] = R[2] - R[6]; r[2] = R[3] - R[1];
+    const double s = std::sqrt((r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1.0) * 0.5;
+    c = c > 1.0 ? 1.0 : c < -1.0 ? -1.0 : c;
+    double theta = std::acos(c);
+    if (s < 1.0e-5) {
+        if (c > 0) { r[0] = r[1] = r[2] = 0.0; return true; }
+        r[0] = std::sqrt(std::max((R[0] + 1.0) * 0.5, 0.0));
+        r[1] = std::sqrt(std::max((R[4] + 1.0) * 0.5, 0.0)) * (R[1] < 0 ? -1.0 : 1.0);
+        r[2] = std::sqrt(std::max((R[8] + 1.0) * 0.5, 0.0)) * (R[2] < 0 ? -1.0 : 1.0);
+        if (std::fabs(r[0]) < std::fabs(r[1]) && std::fabs(r[0]) < std::fabs(r[2]) && (R[5] > 0) != (r[1] * r[2] > 0))
+            r[2] = -r[2];
+        theta /= std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        for (int i = 0; i < 3; ++i) r[i] *= theta;
+        return true;
+    }
+    const double vth = theta / (2.0 * s);
+    for (int i = 0; i < 3; ++i) r[i] *= vth;
+    return true;
+}
+// rotation vector -> matrix (Common/Misc.hpp:11-32)
+void rotation_matrix(const double *r, double *R)
+{
+    const double theta = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    if (theta < 1.0e-6) return;
+    const double a[3] = { r[0] / theta, r[1] / theta, r[2] / theta };
+    const double K[9] = { 0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0 };
+    double K2[9];
+    mat3_mul(K, K, K2);
+    const double sn = std::sin(theta), cs = 1.0 - std::cos(theta);
+    for (int i = 0; i < 9; ++i) R[i] += K[i] * sn + K2[i] * cs;
+}
+}  // namespace
+
+int svcal_stereo_rectify(const double KL[9], const double KR[9], const double R[9], const double T[3],
+                         double left_proj[9], double right_proj[9], double Q[16])
+{
+    if (!KL || !KR || !R || !T || !left_proj || !right_proj || !Q) return SVICP_ERR_ARG;
+    double Rinv[9], eul[3], half[9], peer[9];
+    if (!mat3_inv(R, Rinv) || !rotation_vector(Rinv, eul)) return SVICP_ERR_SINGULAR;
+    for (int i = 0; i < 3; ++i) eul[i] *= -0.5;
+    rotation_matrix(eul, half);
+    mat3_mul(half, Rinv, peer);
+    double t[3];
+    for (int i = 0; i < 3; ++i) t[i] = -(peer[3 * i] * T[0] + peer[3 * i + 1] * T[1] + peer[3 * i + 2] * T[2]);
+    const double n1 = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]), n2 = std::sqrt(t[0] * t[0] + t[1] * t[1]);
+    if (!(n1 > 0.0) || !(n2 > 0.0)) return SVICP_ERR_SINGULAR;
+    const double e1[3] = { t[0] / n1, t[1] / n1, t[2] / n1 }, e2[3] = { -t[1] / n2, t[0] / n2, 0.0 };
+    const double e3[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+    const double rect[9] = { e1[0], e1[1], e1[2], e2[0], e2[1], e2[2], e3[0], e3[1], e3[2] };
+    const double f = (KL[0] + KL[4] + KR[0] + KR[4]) * 0.25;
+    const double newK[9] = { f, 0, (KL[2] + KR[2]) * 0.5, 0, f, (KL[5] + KR[5]) * 0.5, 0, 0, 1 };
+    double a[9];
+    mat3_mul(rect, half, a);
+    mat3_mul(newK, a, left_proj);
+    mat3_mul(rect, peer, a);
+    mat3_mul(newK, a, right_proj);
+    const double Tx = rect[0] * t[0] + rect[1] * t[1] + rect[2] * t[2];
+    for (int i = 0; i < 16; ++i) Q[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    Q[3] = -newK[2]; Q[7] = -newK[5]; Q[10] = 0.0; Q[11] = f; Q[14] = -1.0 / Tx; Q[15] = 0.0;
+    return SVICP_OK;
+}
+
 int svcal_rectify_maps(svcal_ctx *ctx, int width, int height, const double KL[9], const double *distL,
                        const double KR[9], const double *distR, int k_size, const double projL[9],
                        const double projR[9], double *xmap_left, double *ymap_left,

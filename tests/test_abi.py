@@ -30,7 +30,7 @@ def test_calibration_symbols_are_exported():
     from stereovision_amd import _lib, calib
     lib = _lib.load()
     declared = _header_symbols("svcal.h", "svcal_")
-    assert len(declared) == 18
+    assert len(declared) == 19
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in svcal.h but not exported"
     assert sorted(calib.CAL_SYMBOLS) == declared

@@ -299,6 +299,34 @@ def test_dense_and_block_sparse_loops_agree(po):
     assert np.abs(xa[:4] - xb[:4]).max() < 1e-2 and np.abs(xa[-3:] - xb[-3:]).max() < 1e-2
 
 
+# ---- doStereoRectify in the library ---------------------------------------------
+def test_stereo_rectify_in_the_library(po):
+    """svcal_stereo_rectify (CStereoCameraRectification.cpp:13-58 as a C call) against the oracle
+    and the numpy version: the usual rig, no rotation at all, a large rotation, and a rotation
+    matrix that is slightly off orthogonal (the reference's SVD takes the nearest rotation)."""
+    from scipy.spatial.transform import Rotation
+    from stereovision_amd.calib import stereo_rectify, stereo_rectify_native
+    KL = np.array([[535.0, 0, 322.0], [0, 537.0, 243.0], [0, 0, 1]])
+    KR = np.array([[533.0, 0, 318.0], [0, 534.0, 239.0], [0, 0, 1]])
+    T = np.array([-90.0, 1.0, 2.0])
+    for rv in ([0.01, -0.02, 0.005], [0.0, 0.0, 0.0], [0.4, -0.9, 0.6], [2.5, 0.3, -1.0]):
+        R = Rotation.from_rotvec(rv).as_matrix()
+        lp, rp, Q = stereo_rectify_native(KL, KR, R, T)
+        ok, pl, pr, oQ = po.stereo_rectify(KL, KR, R, T)
+        assert ok and np.allclose(lp, pl, atol=1e-9) and np.allclose(rp, pr, atol=1e-9) and np.allclose(Q, oQ, atol=1e-12)
+        npl, npr, nQ = stereo_rectify(KL, KR, R, T)
+        assert np.allclose(lp, npl, atol=1e-9) and np.allclose(rp, npr, atol=1e-9) and np.allclose(Q, nQ, atol=1e-12)
+    R = Rotation.from_rotvec([0.01, -0.02, 0.005]).as_matrix()
+    off = R + 1e-7 * np.arange(9.0).reshape(3, 3)
+    lp, rp, Q = stereo_rectify_native(KL, KR, off, T)
+    lp0, rp0, Q0 = stereo_rectify_native(KL, KR, R, T)
+    assert np.abs(lp - lp0).max() < 1e-3 and np.abs(rp - rp0).max() < 1e-3
+    with pytest.raises(Exception):
+        stereo_rectify_native(KL, KR, np.zeros((3, 3)), T)          # no inverse
+    with pytest.raises(Exception):
+        stereo_rectify_native(KL, KR, np.eye(3), np.array([0.0, 0.0, 5.0]))   # no x / y baseline
+
+
 # ---- rectification maps (CStereoCameraRectification::doImageRectify) -----------
 @pytest.mark.parametrize("size,k", [((640, 480), 5), ((640, 480), 2), ((1921, 1083), 5)])
 def test_rectify_maps_match_oracle(po, size, k):
