@@ -152,7 +152,10 @@ int svicp_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info
  * call them beforehand).  dev_out20: DEVICE memory, 20 doubles, written by the last
  * kernel: the accumulated 4x4 transform row-major, then {status (SVICP_OK or
  * SVICP_ERR_SINGULAR), inliers, sum w b^2, |X|} of the last iteration.  The call
- * returns once the work is queued; svicp_get_history afterwards reports "no run". */
+ * returns once the work is queued; svicp_get_history afterwards reports "no run".
+ * Under a stream capture the call adds kernel nodes only; the recording holds the
+ * source's tile count and the resident buffers' addresses, so record again after a
+ * source of another size. */
 int svicp_run_enqueue(svicp_ctx *ctx, int iterations, double *dev_out20);
 
 /* Iterations of the last successful run on this context (svicp_run,

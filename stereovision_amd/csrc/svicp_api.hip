@@ -1216,8 +1216,8 @@ int svicp_run_enqueue(svicp_ctx *ctx, int iterations, double *dev_out20)
     // cleared by the launch before the one that adds to it).  Everything else is written
     // before it is read: the state by the first solve, the tiles' sums and flags by
     // iteration 0.
-    HIPCHK(hipMemsetAsync(b.totals, 0, sizeof(double) * kNumSums, ctx->stream));
-    HIPCHK(hipMemsetAsync(b.deltas, 0, sizeof(double) * kDeltaRow * 2, ctx->stream));
+    hipLaunchKernelGGL(clear_run_rows_kernel, dim3(1), dim3(64), 0, ctx->stream, b.totals, b.deltas);
+    LAUNCHCHK("clear_run_rows_kernel");
     int rc = enqueue_loop(ctx, iterations, false, b, nullptr, dev_out20);
     if (rc) return rc;
     ctx->cur = iterations > 1 ? 1 : 0;

@@ -1316,6 +1316,16 @@ __global__ void batch_collect_kernel(const BatchPair *__restrict__ pairs, int co
     reinterpret_cast<double *>(out + p)[w] = reinterpret_cast<const double *>(pairs[p].st)[w];
 }
 
+// What a run whose small buffers keep an earlier run's contents takes to be zero when it
+// starts: row 0 of the totals and rows 0 and 1 of the per-iteration changes.  A kernel rather
+// than two memsets, so that a recording of the run holds kernel nodes only.
+__global__ __launch_bounds__(64) void clear_run_rows_kernel(fx_t *totals, fx_t *deltas)
+{
+    const int t = threadIdx.x;
+    if (t < kNumSums) totals[t] = 0;
+    for (int k = t; k < 2 * kDeltaRow; k += 64) deltas[k] = 0;
+}
+
 // One wave: solve the system of iteration `iter` and record the result (the
 // last iteration of a run has no following iteration kernel to do it).
 // dev_out (device memory, or null): the accumulated transform (16 doubles, row-major) and

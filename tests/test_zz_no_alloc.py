@@ -49,6 +49,45 @@ def test_enqueue_matches_run_twice_in_a_row(po):
                 ctx.history()                                     # the history stays in the workspace
 
 
+def test_enqueue_recorded_in_a_graph_and_replayed(po):
+    """The callers this entry point is for: the loop recorded by a stream capture (torch's, in
+    its global capture mode, where an allocation or a synchronising call fails the capture) and
+    launched as a graph.  Device-to-host copies between the launches and a source set again
+    (same size: the recording holds the tile count) must not change what a launch computes."""
+    import torch
+    import stereovision_amd as sv
+    from stereovision_amd import synth
+
+    tgt, nrm, src, _ = synth.make_pair(96, pair=3)
+    with sv.Context(0) as ref, sv.Context(0) as ctx:
+        ref.set_target(tgt, nrm)
+        ref.set_source(src)
+        T_ref, info_ref = ref.run(9)
+        ctx.set_target(tgt, nrm)
+        ctx.set_source(src)
+        out = torch.full((20,), float("nan"), dtype=torch.float64, device="cuda:0")
+        stream = torch.cuda.Stream()
+        ctx.set_stream(stream.cuda_stream)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                ctx.run_enqueue(9, out.data_ptr())
+            for launch in range(5):
+                if launch == 3:
+                    ctx.set_source(src)
+                out.fill_(float("nan"))
+                torch.cuda.synchronize()
+                with torch.cuda.stream(stream):
+                    graph.replay()
+                torch.cuda.synchronize()
+                got = out.cpu().numpy()
+                assert np.abs(got[:16].reshape(4, 4) - T_ref).max() < 1e-9, launch
+                assert got[16] == 0 and got[17] == info_ref.inliers, launch
+            del graph
+        finally:
+            ctx.use_own_stream()
+
+
 def test_enqueue_rejects_what_exceeds_the_workspace(synth32):
     import stereovision_amd as sv
     with sv.Context(0) as ctx:
