@@ -19,6 +19,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -46,6 +47,9 @@ def parse():
     ap.add_argument("--extras", type=int, default=1,
                     help="1: also time normal estimation, point-to-point ICP, rectification maps "
                          "and the drop-in call")
+    ap.add_argument("--leg-budget-s", type=float, default=480.0,
+                    help="seconds the legs after the headline measurement may take in all before "
+                         "the line is written without the unfinished ones")
     ap.add_argument("--cal-views", type=int, default=2000,
                     help="views of the calibration leg (11 x 8 board each); 0 disables the leg")
     return ap.parse_args()
@@ -240,306 +244,9 @@ def main():
     stream_copy_gbs = 10 * 2.0 * a.numel() / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
     del a, b
 
-    # ---- sharded leg: one large pair, source split over the ranks, the loop inside the
-    # library at every N (N = 1 included: a one-rank communicator, the same graph) ----
-    sharded = None
-    value_sharded = None
-    if args.sharded_side > 0:
-        st, sn, ss, spose = synth.make_pair(args.sharded_side, pair=0, inlier_frac=0.7)
-        b0, e0 = shard_bounds(len(ss), world, rank)
-        sctx = sv.Context(local)
-        sctx.set_target(st, sn)
-        sctx.set_source(np.ascontiguousarray(ss[b0:e0]))
-        n_sh = len(ss)
-        del ss
-        native = backend == "nccl"
-        if native:
-            init_comm(sctx)
-            run_once = lambda: run_sharded_native(sctx, args.iters)
-        else:
-            eng = HipShardEngine(sctx, f"cuda:{local}")
-            run_once = lambda: run_sharded(eng, args.iters)
-        Ts, sinfo = run_once()
-        barrier()
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            Ts, sinfo = run_once()
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t0)
-        value_sharded = reps * args.iters / dt
-        captured, comm_world = sctx.shard_run_mode() if native else (False, world)
-        sharded = {
-            "workload": f"configs[2]: one {args.sharded_side}^2-point pair (start pose with 70 % of the "
-                        f"source within the threshold), source split over {world} rank(s), target "
-                        "replicated, one all-reduce of 128 64-bit fixed-point sums per iteration",
-            "iters_per_s": value_sharded, "scaling": "strong", "points": n_sh,
-            "path": "svicp_shard_run (iteration kernel + ncclAllReduce per iteration on one stream)"
-                    if native else "stepping calls + torch.distributed (rehearsal backend)",
-            "graph_captured": bool(captured), "communicator_world": comm_world,
-            "pose_error": float(np.abs(Ts @ spose - np.eye(4)).max()),
-            "measured_on": "this run's GPUs; N > 1 has not been measured on hardware by the builder",
-        }
-        if native:
-            sctx.comm_destroy()
-        sctx.close()
-
-    # ---- batched leg: configs[3]'s per-GPU slice, 512 independent 65536-point pairs per
-    # rank in one arena batch (one launch per iteration for all); ranks take disjoint pairs,
-    # no collective while iterating, one gather of the transforms at the end ----
-    batched = None
-    if args.batch_pairs > 0:
-        total_pairs = args.batch_pairs * world
-        first, last = pair_bounds(total_pairs, world, rank)
-        tg, nr, sr = [], [], []
-        for pid in range(first, last):
-            bt, bn, bs, _ = synth.make_pair(256, pair=pid, pose=synth.small_pose(pid))
-            tg.append(bt); nr.append(bn); sr.append(bs)
-        eng = HipBatchEngine(tg, nr, sr, device=local)
-        del tg, nr, sr
-        _, setup_ms, arena_bytes = eng.batch.info()
-        for _ in range(3):
-            eng.run(args.iters)
-        barrier()
-        t0 = time.perf_counter()
-        reps = 10
-        run_ms, dev_ms = [], []
-        for _ in range(reps):
-            t1 = time.perf_counter()
-            eng.run(args.iters)
-            run_ms.append((time.perf_counter() - t1) * 1e3)
-            dev_ms.append(eng.batch.last_ms())
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t0)
-        t0 = time.perf_counter()
-        Tall, _ = run_pairs_split(eng, total_pairs, args.iters)
-        gather_s = time.perf_counter() - t0
-        batched = {
-            "workload": f"configs[3] slice: {args.batch_pairs} independent pairs of 65536 points per rank "
-                        f"({total_pairs} in all), {args.iters} iterations, per-pair pose, one launch per "
-                        "iteration for all pairs of a rank",
-            "pair_iterations_per_s": world * reps * args.batch_pairs * args.iters / dt,
-            "point_iterations_per_s": world * reps * args.batch_pairs * args.iters * 65536 / dt,
-            "device_ms_per_run": eng.batch.last_ms(),
-            "host_ms_per_run": dt / reps * 1e3,
-            "host_ms_runs": [round(x, 2) for x in run_ms], "device_ms_runs": [round(x, 2) for x in dev_ms],
-            "setup_ms": setup_ms, "arena_GiB": arena_bytes / 2 ** 30,
-            "run_and_gather_ms": gather_s * 1e3,
-            "scaling": "weak",
-        }
-        eng.close()
-
-    # ---- calibration leg: residual + Jacobian evaluations of the stereo refinement,
-    # views split over the ranks, one 272-double all-reduce per evaluation ----
-    calibration = None
-    if args.cal_views >= world:
-        from stereovision_amd.calib import HipCalEngine, evaluate_sharded, view_bounds
-        V = args.cal_views
-        cw, cl, cr, _, cstart = synth.make_stereo_views(views=V)
-        vb, ve = view_bounds(V, world, rank)
-        eng = HipCalEngine(cw, cl[vb:ve], cr[vb:ve], f"cuda:{local}")
-        reps = 200
-        if distributed:
-            for _ in range(5):
-                evaluate_sharded(eng, cstart, 5, V, vb, ve, fetch=False)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                evaluate_sharded(eng, cstart, 5, V, vb, ve, fetch=False)
-            barrier()
-            dt = time.perf_counter() - t0
-            eval_ms = max_over_ranks(dt) / reps * 1e3
-        else:
-            eng.set_params(cstart, 5)
-            eval_ms = eng.ev.time_eval(reps)      # HIP events around back-to-back evaluations
-        C = cl.shape[1]
-        cal_bytes = 56.0 * V * C + 48.0 * V
-        # fp64 operations per (view, corner, camera), five distortion terms, the least the
-        # central differences need: 13 geometric stages (12 multiply-adds of the 3 x 4 product,
-        # two quotients, r: 26 operations), 31 pixel stages (distortion polynomial, tangential
-        # terms, intrinsics: 36), 30 central differences (a subtraction and a quotient each), the
-        # residual, and two rank-1 updates of the 16 x 16 Gram matrix on the matrix cores
-        # (512 each); an operation is one add, multiply or divide.  (The kernel deals one
-        # component of a corner's rows to a lane and spends 32 stages of each kind.)
-        flops_unit = 13 * 26 + 31 * 36 + 30 * 2 + 2 + 2 * 512
-        flops_eval = flops_unit * 2.0 * V * C
-        tf = flops_eval / (eval_ms * 1e-3) / 1e12
-        calibration = {
-            "workload": f"configs[4]: stereo reprojection residual + central-difference Jacobian reduced to "
-                        f"block-sparse normal equations, {V} views x {C} corners "
-                        f"({4 * V * C} residual rows, {18 + 6 * V + 6} parameters), "
-                        f"views split over {world} rank(s)",
-            "evaluations_per_s": 1e3 / eval_ms, "ms_per_evaluation": eval_ms, "dtype": "f64",
-            "algorithmic_GBs": cal_bytes / (eval_ms * 1e-3) / 1e9,
-            "scaling": "strong",
-            "roofline": {
-                "bound": "fp64 vector", "kernel": "cal_eval_kernel<5> + cal_reduce_kernel",
-                "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TF,
-                "flops_per_view_corner_camera": flops_unit, "units": 2 * V * C,
-                "note": "the loop issues 124 vector instructions (102 fp64) and 2 matrix instructions per "
-                        "four corners at 6.6 SIMD cycles per wave instruction, whatever the occupancy; "
-                        "HBM is not the bound (algorithmic_GBs)",
-                "peak_source": "half the fp32 vector peak (157.3 TF) of MI355X_MICROARCH.md",
-            },
-        }
-        if not distributed:
-            # the caller of the evaluation: one damped step of the refinement loop on the device
-            # (per-view blocks eliminated first), step and predicted decrease copied back
-            eng.ev.eval()
-            eng.ev.solve_damped(1e-3)
-            t0 = time.perf_counter()
-            for _ in range(20):
-                eng.ev.solve_damped(1e-3)
-            calibration["damped_step_ms"] = (time.perf_counter() - t0) / 20 * 1e3
-        else:
-            # the same step with the views split: every rank eliminates its own views, the
-            # shared system is summed over the ranks and solved by each, the step is gathered
-            from stereovision_amd.calib import solve_damped_sharded
-            evaluate_sharded(eng, cstart, 5, V, vb, ve, fetch=False)
-            solve_damped_sharded(eng, 1e-3, 5, V, vb, ve)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(20):
-                solve_damped_sharded(eng, 1e-3, 5, V, vb, ve)
-            barrier()
-            calibration["damped_step_ms"] = max_over_ranks(time.perf_counter() - t0) / 20 * 1e3
-        if rank == 0 and world == 1 and args.cpu_iters > 0:
-            from oracle import pyoracle as po
-            t0 = time.perf_counter()
-            nrep = 0
-            while time.perf_counter() - t0 < 5.0:
-                po.stereo_eval_sparse(cstart, 5, cw, cl, cr, want_residual=False)
-                nrep += 1
-            calibration["cpu_baseline"] = {
-                "value": nrep / (time.perf_counter() - t0), "unit": "evaluations/s", "cores": 1,
-                "kind": "port",
-                "sample": f"{nrep} block-sparse evaluations of the same {V}-view problem "
-                          "(oracle/cal_oracle.c; the reference's dense Jacobian of "
-                          f"{4 * V * C} x {18 + 6 * V + 6} doubles cannot be allocated)",
-            }
-
-    # ---- the rows next to the hot path, rank 0 only, small and bounded: normal estimation,
-    # the point-to-point variant, the rectification maps, the drop-in call from host buffers;
-    # each with the CPU checker beside it
-    neighbours = None
-    dropin = None
-    if rank == 0 and args.extras:
-        neighbours = {}
-        ectx = sv.Context(local)
-        ectx.set_target(tgt, None)                              # allocations
-        t0 = time.perf_counter()
-        ectx.set_target(tgt, None)                              # grid + 20-NN + eigenvectors
-        t_est = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        ectx.set_target(tgt, nrm)
-        t_given = time.perf_counter() - t0
-        neighbours["normal_estimation"] = {
-            "workload": f"calcNormals on {len(tgt)} target points (20-NN, uncentred moments, "
-                        "smallest eigenvector): the whole set_target host call, upload and grid "
-                        "build included (the CPU figure includes its tree build)",
-            "ms": t_est * 1e3, "set_target_with_given_normals_ms": t_given * 1e3,
-            "note": "the second call uploads 12 B of normals per point instead of estimating them"}
-        # the drop-in call as CPoint2PlaneICP::run of the compat classes makes it
-        # (CPoint2PlaneICP.cpp:31-62): host buffer in, 30 iterations, moved cloud back out
-        from stereovision_amd.icp import pinned_empty
-
-        def call(buf_in, buf_out):
-            t0 = time.perf_counter()
-            ectx.set_source(buf_in)
-            ectx.run(args.iters)
-            ectx.get_source(buf_out)
-            return (time.perf_counter() - t0) * 1e3
-        out_pageable = np.empty_like(src)
-        pin_in, pin_out = pinned_empty(src.shape), pinned_empty(src.shape)
-        pin_in[:] = src
-        call(src, out_pageable); call(pin_in, pin_out)
-        dropin = {
-            "workload": f"set_source + {args.iters} iterations + get_source, {n} points, host buffers "
-                        "(PCIe inclusive; never `value`)",
-            "dropin_call_ms": float(np.mean([call(src, out_pageable) for _ in range(5)])),
-            "dropin_call_ms_pinned_buffers": float(np.mean([call(pin_in, pin_out) for _ in range(5)])),
-            "note": "pinned: the clouds live in svicp_host_alloc memory, as the drop-in CTxtReader allocates them",
-        }
-        ectx.close()
-        pctx = sv.Context(local, dist_threshold=15.0)
-        pctx.set_target(tgt, tgt)
-        pctx.set_source(src)
-        pctx.run_point2point(args.iters)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            Tp, _ = pctx.run_point2point(args.iters)
-        dtp = (time.perf_counter() - t0) / 5
-        neighbours["point_to_point"] = {
-            "workload": f"CPoint2PointICP, same {n}-point pair, threshold 15, {args.iters} iterations",
-            "iters_per_s": args.iters / dtp}
-        pctx.close()
-        from stereovision_amd.calib import rectify_maps, stereo_rectify
-        KL = np.array([[1400.0, 0, 960.0], [0, 1400.0, 540.0], [0, 0, 1]])
-        KR = np.array([[1395.0, 0, 955.0], [0, 1398.0, 545.0], [0, 0, 1]])
-        dL = np.array([-0.28, 0.09, 1e-3, -5e-4, 0.01])
-        dR = np.array([-0.27, 0.08, -7e-4, 4e-4, -0.02])
-        cr_, sr_ = np.cos(0.01), np.sin(0.01)
-        Rrig = np.array([[cr_, 0, sr_], [0, 1, 0], [-sr_, 0, cr_]])
-        pl, pr, _ = stereo_rectify(KL, KR, Rrig, [-90.0, 1.0, 2.0])
-        rectify_maps(1920, 1080, KL, dL, KR, dR, pl, pr, device=local)
-        *_, rect_ms = rectify_maps(1920, 1080, KL, dL, KR, dR, pl, pr, device=local, return_ms=True)
-        neighbours["rectify_maps"] = {
-            "workload": "doImageRectify, 1920 x 1080, both cameras, five distortion terms",
-            "kernel_ms": rect_ms, "GBs": 1920 * 1080 * 32 / (rect_ms * 1e-3) / 1e9}
-        if world == 1 and args.cpu_iters > 0:
-            from oracle import pyoracle as po
-            sub = 1 << 17                                       # a bounded sample for the CPU
-            t0 = time.perf_counter()
-            po.calc_normals(po.KDTree(tgt[:sub]), threads=1)
-            neighbours["normal_estimation"]["cpu_baseline"] = {
-                "value": sub / (time.perf_counter() - t0), "unit": "points/s", "cores": 1, "kind": "port",
-                "sample": f"first {sub} target points (tree build included)",
-                "gpu_points_per_s": len(tgt) / t_est}
-            ptree = po.KDTree(tgt)
-            t0 = time.perf_counter()
-            po.icp_point2point(ptree, src, 5, faithful=True, threads=1, history=False)
-            neighbours["point_to_point"]["cpu_baseline"] = {
-                "value": 5 / (time.perf_counter() - t0), "unit": "iters/s", "cores": 1, "kind": "port",
-                "sample": "5 iterations of the same pair, tree build excluded"}
-            t0 = time.perf_counter()
-            po.rectify_maps(1920, 1080, KL, dL, KR, dR, pl, pr)
-            neighbours["rectify_maps"]["cpu_baseline"] = {
-                "value": (time.perf_counter() - t0) * 1e3, "unit": "ms", "cores": 1, "kind": "port",
-                "sample": "the same 1920 x 1080 maps (the inverse projection formed once, not per "
-                          "pixel as the reference does)"}
-
-    # ---- CPU baseline: the oracle on the same pair, one thread ------------
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_iters > 0:
-        from oracle import pyoracle as po
-        tree = po.KDTree(tgt)                       # index build excluded, as test.cpp:20-21
-        t0 = time.perf_counter()
-        r = po.icp_point2plane(tree, nrm, src, args.cpu_iters, faithful=True, threads=1,
-                               history=False)
-        dt = time.perf_counter() - t0
-        Xg, _ = ctx.history()
-        cpu = {
-            "value": args.cpu_iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": f"{args.cpu_iters} of {args.iters} iterations of the same "
-                      f"{n}-point pair, kd-tree build excluded, restated reference "
-                      "(oracle/icp_oracle.c; the reference needs FLANN+Eigen and cannot be built)",
-            "host_cpus": os.cpu_count(),
-            "max_abs_X_diff_vs_gpu": float(np.abs(Xg[: args.cpu_iters] - r["X"]).max()),
-        }
-
-    cpu_all = None
-    if cpu is not None:
-        threads = min(po.max_threads(), 16)
-        t0 = time.perf_counter()
-        po.icp_point2plane(tree, nrm, src, args.cpu_iters, faithful=True, threads=threads, history=False)
-        cpu_all = {"value": args.cpu_iters / (time.perf_counter() - t0), "unit": "iters/s",
-                   "cores": threads, "kind": "port",
-                   "sample": "as cpu_baseline, the nearest-neighbour queries spread over the host "
-                             "threads (the reference itself is single-threaded)"}
-
-    if rank == 0:
-        out = {
+    def build_out():
+        # read when the line is written: the legs below fill their variables as they finish
+        return {
             "metric": "point-to-plane ICP iters/s at 1M pts",
             "value": value,
             "unit": "iters/s",
@@ -643,8 +350,347 @@ def main():
             "dropin": dropin,
             "neighbouring_rows": neighbours,
         }
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    # ---- everything below is secondary to `value`.  A leg that raises leaves its error in the
+    # line instead of taking the headline with it; a leg that does not come back (a collective
+    # that never completes on a machine this code has not met) is cut off by a watchdog, which
+    # writes the line with what has finished and ends the process.
+    sharded = value_sharded = batched = calibration = neighbours = dropin = cpu = cpu_all = None
+    failed = {}
+    current = ["headline"]
+    written = threading.Lock()
+    finished = threading.Event()
+
+    def write_line(unfinished=None):
+        if not written.acquire(blocking=False):
+            return
+        if rank == 0:
+            out = build_out()
+            if failed:
+                out["failed_legs"] = failed
+            if unfinished:
+                out["unfinished_leg"] = unfinished
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    def watchdog():
+        if not finished.wait(args.leg_budget_s):
+            write_line(f"{current[0]}: no return within {args.leg_budget_s} s of the headline measurement")
+            os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+
+    def guard(name, leg):
+        current[0] = name
+        try:
+            return leg()
+        except Exception as e:                      # noqa: BLE001 - reported in the line
+            failed[name] = f"{type(e).__name__}: {e}"[:400]
+            return None
+
+    # ---- sharded leg: one large pair, source split over the ranks, the loop inside the
+    # library at every N (N = 1 included: a one-rank communicator, the same graph) ----
+    def leg_sharded():
+        nonlocal value_sharded
+        st, sn, ss, spose = synth.make_pair(args.sharded_side, pair=0, inlier_frac=0.7)
+        b0, e0 = shard_bounds(len(ss), world, rank)
+        sctx = sv.Context(local)
+        sctx.set_target(st, sn)
+        sctx.set_source(np.ascontiguousarray(ss[b0:e0]))
+        n_sh = len(ss)
+        del ss
+        native = backend == "nccl"
+        if native:
+            init_comm(sctx)
+            run_once = lambda: run_sharded_native(sctx, args.iters)
+        else:
+            eng = HipShardEngine(sctx, f"cuda:{local}")
+            run_once = lambda: run_sharded(eng, args.iters)
+        Ts, sinfo = run_once()
+        barrier()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            Ts, sinfo = run_once()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        value_sharded = reps * args.iters / dt
+        captured, comm_world = sctx.shard_run_mode() if native else (False, world)
+        sharded = {
+            "workload": f"configs[2]: one {args.sharded_side}^2-point pair (start pose with 70 % of the "
+                        f"source within the threshold), source split over {world} rank(s), target "
+                        "replicated, one all-reduce of 128 64-bit fixed-point sums per iteration",
+            "iters_per_s": value_sharded, "scaling": "strong", "points": n_sh,
+            "path": "svicp_shard_run (iteration kernel + ncclAllReduce per iteration on one stream)"
+                    if native else "stepping calls + torch.distributed (rehearsal backend)",
+            "graph_captured": bool(captured), "communicator_world": comm_world,
+            "pose_error": float(np.abs(Ts @ spose - np.eye(4)).max()),
+            "measured_on": "this run's GPUs; N > 1 has not been measured on hardware by the builder",
+        }
+        if native:
+            sctx.comm_destroy()
+        sctx.close()
+        return sharded
+    if args.sharded_side > 0:
+        sharded = guard("sharded", leg_sharded)
+
+    # ---- batched leg: configs[3]'s per-GPU slice, 512 independent 65536-point pairs per
+    # rank in one arena batch (one launch per iteration for all); ranks take disjoint pairs,
+    # no collective while iterating, one gather of the transforms at the end ----
+    def leg_batched():
+        total_pairs = args.batch_pairs * world
+        first, last = pair_bounds(total_pairs, world, rank)
+        tg, nr, sr = [], [], []
+        for pid in range(first, last):
+            bt, bn, bs, _ = synth.make_pair(256, pair=pid, pose=synth.small_pose(pid))
+            tg.append(bt); nr.append(bn); sr.append(bs)
+        eng = HipBatchEngine(tg, nr, sr, device=local)
+        del tg, nr, sr
+        _, setup_ms, arena_bytes = eng.batch.info()
+        for _ in range(3):
+            eng.run(args.iters)
+        barrier()
+        t0 = time.perf_counter()
+        reps = 10
+        run_ms, dev_ms = [], []
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            eng.run(args.iters)
+            run_ms.append((time.perf_counter() - t1) * 1e3)
+            dev_ms.append(eng.batch.last_ms())
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        Tall, _ = run_pairs_split(eng, total_pairs, args.iters)
+        gather_s = time.perf_counter() - t0
+        batched = {
+            "workload": f"configs[3] slice: {args.batch_pairs} independent pairs of 65536 points per rank "
+                        f"({total_pairs} in all), {args.iters} iterations, per-pair pose, one launch per "
+                        "iteration for all pairs of a rank",
+            "pair_iterations_per_s": world * reps * args.batch_pairs * args.iters / dt,
+            "point_iterations_per_s": world * reps * args.batch_pairs * args.iters * 65536 / dt,
+            "device_ms_per_run": eng.batch.last_ms(),
+            "host_ms_per_run": dt / reps * 1e3,
+            "host_ms_runs": [round(x, 2) for x in run_ms], "device_ms_runs": [round(x, 2) for x in dev_ms],
+            "setup_ms": setup_ms, "arena_GiB": arena_bytes / 2 ** 30,
+            "run_and_gather_ms": gather_s * 1e3,
+            "scaling": "weak",
+        }
+        eng.close()
+        return batched
+    if args.batch_pairs > 0:
+        batched = guard("batched", leg_batched)
+
+    # ---- calibration leg: residual + Jacobian evaluations of the stereo refinement,
+    # views split over the ranks, one 272-double all-reduce per evaluation ----
+    def leg_calibration():
+        from stereovision_amd.calib import HipCalEngine, evaluate_sharded, view_bounds
+        V = args.cal_views
+        cw, cl, cr, _, cstart = synth.make_stereo_views(views=V)
+        vb, ve = view_bounds(V, world, rank)
+        eng = HipCalEngine(cw, cl[vb:ve], cr[vb:ve], f"cuda:{local}")
+        reps = 200
+        if distributed:
+            for _ in range(5):
+                evaluate_sharded(eng, cstart, 5, V, vb, ve, fetch=False)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                evaluate_sharded(eng, cstart, 5, V, vb, ve, fetch=False)
+            barrier()
+            dt = time.perf_counter() - t0
+            eval_ms = max_over_ranks(dt) / reps * 1e3
+        else:
+            eng.set_params(cstart, 5)
+            eval_ms = eng.ev.time_eval(reps)      # HIP events around back-to-back evaluations
+        C = cl.shape[1]
+        cal_bytes = 56.0 * V * C + 48.0 * V
+        # fp64 operations per (view, corner, camera), five distortion terms, the least the
+        # central differences need: 13 geometric stages (12 multiply-adds of the 3 x 4 product,
+        # two quotients, r: 26 operations), 31 pixel stages (distortion polynomial, tangential
+        # terms, intrinsics: 36), 30 central differences (a subtraction and a quotient each), the
+        # residual, and two rank-1 updates of the 16 x 16 Gram matrix on the matrix cores
+        # (512 each); an operation is one add, multiply or divide.  (The kernel deals one
+        # component of a corner's rows to a lane and spends 32 stages of each kind.)
+        flops_unit = 13 * 26 + 31 * 36 + 30 * 2 + 2 + 2 * 512
+        flops_eval = flops_unit * 2.0 * V * C
+        tf = flops_eval / (eval_ms * 1e-3) / 1e12
+        calibration = {
+            "workload": f"configs[4]: stereo reprojection residual + central-difference Jacobian reduced to "
+                        f"block-sparse normal equations, {V} views x {C} corners "
+                        f"({4 * V * C} residual rows, {18 + 6 * V + 6} parameters), "
+                        f"views split over {world} rank(s)",
+            "evaluations_per_s": 1e3 / eval_ms, "ms_per_evaluation": eval_ms, "dtype": "f64",
+            "algorithmic_GBs": cal_bytes / (eval_ms * 1e-3) / 1e9,
+            "scaling": "strong",
+            "roofline": {
+                "bound": "fp64 vector", "kernel": "cal_eval_kernel<5> + cal_reduce_kernel",
+                "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TF,
+                "flops_per_view_corner_camera": flops_unit, "units": 2 * V * C,
+                "note": "the loop issues 124 vector instructions (102 fp64) and 2 matrix instructions per "
+                        "four corners at 6.6 SIMD cycles per wave instruction, whatever the occupancy; "
+                        "HBM is not the bound (algorithmic_GBs)",
+                "peak_source": "half the fp32 vector peak (157.3 TF) of MI355X_MICROARCH.md",
+            },
+        }
+        if not distributed:
+            # the caller of the evaluation: one damped step of the refinement loop on the device
+            # (per-view blocks eliminated first), step and predicted decrease copied back
+            eng.ev.eval()
+            eng.ev.solve_damped(1e-3)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                eng.ev.solve_damped(1e-3)
+            calibration["damped_step_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+        else:
+            # the same step with the views split: every rank eliminates its own views, the
+            # shared system is summed over the ranks and solved by each, the step is gathered
+            from stereovision_amd.calib import solve_damped_sharded
+            evaluate_sharded(eng, cstart, 5, V, vb, ve, fetch=False)
+            solve_damped_sharded(eng, 1e-3, 5, V, vb, ve)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                solve_damped_sharded(eng, 1e-3, 5, V, vb, ve)
+            barrier()
+            calibration["damped_step_ms"] = max_over_ranks(time.perf_counter() - t0) / 20 * 1e3
+        if rank == 0 and world == 1 and args.cpu_iters > 0:
+            from oracle import pyoracle as po
+            t0 = time.perf_counter()
+            nrep = 0
+            while time.perf_counter() - t0 < 5.0:
+                po.stereo_eval_sparse(cstart, 5, cw, cl, cr, want_residual=False)
+                nrep += 1
+            calibration["cpu_baseline"] = {
+                "value": nrep / (time.perf_counter() - t0), "unit": "evaluations/s", "cores": 1,
+                "kind": "port",
+                "sample": f"{nrep} block-sparse evaluations of the same {V}-view problem "
+                          "(oracle/cal_oracle.c; the reference's dense Jacobian of "
+                          f"{4 * V * C} x {18 + 6 * V + 6} doubles cannot be allocated)",
+            }
+        return calibration
+    if args.cal_views >= world:
+        calibration = guard("calibration", leg_calibration)
+
+    # ---- the rows next to the hot path, rank 0 only, small and bounded: normal estimation,
+    # the point-to-point variant, the rectification maps, the drop-in call from host buffers;
+    # each with the CPU checker beside it
+    def leg_extras():
+        nonlocal dropin
+        neighbours = {}
+        ectx = sv.Context(local)
+        ectx.set_target(tgt, None)                              # allocations
+        t0 = time.perf_counter()
+        ectx.set_target(tgt, None)                              # grid + 20-NN + eigenvectors
+        t_est = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ectx.set_target(tgt, nrm)
+        t_given = time.perf_counter() - t0
+        neighbours["normal_estimation"] = {
+            "workload": f"calcNormals on {len(tgt)} target points (20-NN, uncentred moments, "
+                        "smallest eigenvector): the whole set_target host call, upload and grid "
+                        "build included (the CPU figure includes its tree build)",
+            "ms": t_est * 1e3, "set_target_with_given_normals_ms": t_given * 1e3,
+            "note": "the second call uploads 12 B of normals per point instead of estimating them"}
+        # the drop-in call as CPoint2PlaneICP::run of the compat classes makes it
+        # (CPoint2PlaneICP.cpp:31-62): host buffer in, 30 iterations, moved cloud back out
+        from stereovision_amd.icp import pinned_empty
+
+        def call(buf_in, buf_out):
+            t0 = time.perf_counter()
+            ectx.set_source(buf_in)
+            ectx.run(args.iters)
+            ectx.get_source(buf_out)
+            return (time.perf_counter() - t0) * 1e3
+        out_pageable = np.empty_like(src)
+        pin_in, pin_out = pinned_empty(src.shape), pinned_empty(src.shape)
+        pin_in[:] = src
+        call(src, out_pageable); call(pin_in, pin_out)
+        dropin = {
+            "workload": f"set_source + {args.iters} iterations + get_source, {n} points, host buffers "
+                        "(PCIe inclusive; never `value`)",
+            "dropin_call_ms": float(np.mean([call(src, out_pageable) for _ in range(5)])),
+            "dropin_call_ms_pinned_buffers": float(np.mean([call(pin_in, pin_out) for _ in range(5)])),
+            "note": "pinned: the clouds live in svicp_host_alloc memory, as the drop-in CTxtReader allocates them",
+        }
+        ectx.close()
+        pctx = sv.Context(local, dist_threshold=15.0)
+        pctx.set_target(tgt, tgt)
+        pctx.set_source(src)
+        pctx.run_point2point(args.iters)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            Tp, _ = pctx.run_point2point(args.iters)
+        dtp = (time.perf_counter() - t0) / 5
+        neighbours["point_to_point"] = {
+            "workload": f"CPoint2PointICP, same {n}-point pair, threshold 15, {args.iters} iterations",
+            "iters_per_s": args.iters / dtp}
+        pctx.close()
+        from stereovision_amd.calib import rectify_maps, stereo_rectify
+        KL = np.array([[1400.0, 0, 960.0], [0, 1400.0, 540.0], [0, 0, 1]])
+        KR = np.array([[1395.0, 0, 955.0], [0, 1398.0, 545.0], [0, 0, 1]])
+        dL = np.array([-0.28, 0.09, 1e-3, -5e-4, 0.01])
+        dR = np.array([-0.27, 0.08, -7e-4, 4e-4, -0.02])
+        cr_, sr_ = np.cos(0.01), np.sin(0.01)
+        Rrig = np.array([[cr_, 0, sr_], [0, 1, 0], [-sr_, 0, cr_]])
+        pl, pr, _ = stereo_rectify(KL, KR, Rrig, [-90.0, 1.0, 2.0])
+        rectify_maps(1920, 1080, KL, dL, KR, dR, pl, pr, device=local)
+        *_, rect_ms = rectify_maps(1920, 1080, KL, dL, KR, dR, pl, pr, device=local, return_ms=True)
+        neighbours["rectify_maps"] = {
+            "workload": "doImageRectify, 1920 x 1080, both cameras, five distortion terms",
+            "kernel_ms": rect_ms, "GBs": 1920 * 1080 * 32 / (rect_ms * 1e-3) / 1e9}
+        if world == 1 and args.cpu_iters > 0:
+            from oracle import pyoracle as po
+            sub = 1 << 17                                       # a bounded sample for the CPU
+            t0 = time.perf_counter()
+            po.calc_normals(po.KDTree(tgt[:sub]), threads=1)
+            neighbours["normal_estimation"]["cpu_baseline"] = {
+                "value": sub / (time.perf_counter() - t0), "unit": "points/s", "cores": 1, "kind": "port",
+                "sample": f"first {sub} target points (tree build included)",
+                "gpu_points_per_s": len(tgt) / t_est}
+            ptree = po.KDTree(tgt)
+            t0 = time.perf_counter()
+            po.icp_point2point(ptree, src, 5, faithful=True, threads=1, history=False)
+            neighbours["point_to_point"]["cpu_baseline"] = {
+                "value": 5 / (time.perf_counter() - t0), "unit": "iters/s", "cores": 1, "kind": "port",
+                "sample": "5 iterations of the same pair, tree build excluded"}
+            t0 = time.perf_counter()
+            po.rectify_maps(1920, 1080, KL, dL, KR, dR, pl, pr)
+            neighbours["rectify_maps"]["cpu_baseline"] = {
+                "value": (time.perf_counter() - t0) * 1e3, "unit": "ms", "cores": 1, "kind": "port",
+                "sample": "the same 1920 x 1080 maps (the inverse projection formed once, not per "
+                          "pixel as the reference does)"}
+
+    # ---- CPU baseline: the oracle on the same pair, one thread ------------
+    current[0] = "cpu_baseline"
+    if rank == 0 and world == 1 and args.cpu_iters > 0:
+        from oracle import pyoracle as po
+        tree = po.KDTree(tgt)                       # index build excluded, as test.cpp:20-21
+        t0 = time.perf_counter()
+        r = po.icp_point2plane(tree, nrm, src, args.cpu_iters, faithful=True, threads=1,
+                               history=False)
+        dt = time.perf_counter() - t0
+        Xg, _ = ctx.history()
+        cpu = {
+            "value": args.cpu_iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": f"{args.cpu_iters} of {args.iters} iterations of the same "
+                      f"{n}-point pair, kd-tree build excluded, restated reference "
+                      "(oracle/icp_oracle.c; the reference needs FLANN+Eigen and cannot be built)",
+            "host_cpus": os.cpu_count(),
+            "max_abs_X_diff_vs_gpu": float(np.abs(Xg[: args.cpu_iters] - r["X"]).max()),
+        }
+
+    if cpu is not None:
+        threads = min(po.max_threads(), 16)
+        t0 = time.perf_counter()
+        po.icp_point2plane(tree, nrm, src, args.cpu_iters, faithful=True, threads=threads, history=False)
+        cpu_all = {"value": args.cpu_iters / (time.perf_counter() - t0), "unit": "iters/s",
+                   "cores": threads, "kind": "port",
+                   "sample": "as cpu_baseline, the nearest-neighbour queries spread over the host "
+                             "threads (the reference itself is single-threaded)"}
+
+    finished.set()
+    write_line()
     ctx.close()
     if distributed:
         dist.destroy_process_group()
