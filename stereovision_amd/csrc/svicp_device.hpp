@@ -884,6 +884,7 @@ __device__ __forceinline__ void iterate_tile(
     __shared__ int wcount[NP][kItThreads / 64];
     __shared__ double shRT[12];
     __shared__ float4 found[kItThreads / 64][2];
+    __shared__ __attribute__((aligned(16))) int wave_moved[kItThreads / 64];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float *const sx_in = INPLACE ? sx_out : sx_in_, *const sy_in = INPLACE ? sy_out : sy_in_,
@@ -1033,7 +1034,13 @@ __device__ __forceinline__ void iterate_tile(
     // like that. ----
     SVICP_STAMP(2);
     if (APPLY && CERTIFY && in_place) {
-        if (!__syncthreads_or(any_moved ? 1 : 0)) return;      // (its flag bit stays clear)
+        // one barrier: every wave leaves its own verdict in its own word (nothing to clear
+        // beforehand), and every thread reads the four words at once
+        static_assert(kItThreads / 64 == 4, "the four verdicts are read as one 16-byte word");
+        if (lane == 0) wave_moved[wv] = __ballot(any_moved) != 0ull ? 1 : 0;
+        __syncthreads();
+        const int4 verdicts = *reinterpret_cast<const int4 *>(wave_moved);
+        if (!(verdicts.x | verdicts.y | verdicts.z | verdicts.w)) return;   // (its flag bit stays clear)
     }
     // (the tile's flag bit is raised at the very end: an atomic stays in the wave's count of
     // outstanding memory operations for microseconds, and every later load would wait behind it)
