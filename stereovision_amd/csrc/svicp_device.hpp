@@ -1037,7 +1037,8 @@ __device__ __forceinline__ void iterate_tile(
         // one barrier: every wave leaves its own verdict in its own word (nothing to clear
         // beforehand), and every thread reads the four words at once
         static_assert(kItThreads / 64 == 4, "the four verdicts are read as one 16-byte word");
-        if (lane == 0) wave_moved[wv] = __ballot(any_moved) != 0ull ? 1 : 0;
+        const int wave_verdict = __ballot(any_moved) != 0ull ? 1 : 0;       // (every lane votes)
+        if (lane == 0) wave_moved[wv] = wave_verdict;
         __syncthreads();
         const int4 verdicts = *reinterpret_cast<const int4 *>(wave_moved);
         if (!(verdicts.x | verdicts.y | verdicts.z | verdicts.w)) return;   // (its flag bit stays clear)
