@@ -625,10 +625,16 @@ __device__ inline void solve_and_update(const SumsInFlight &sums, fx_t *totals,
     // lane r < 6 takes row r of the matrix and element r of the right-hand side
     const int rr6 = t < 6 ? t : 5;
     double m[6];
+    // which lane holds element (rr6, c): the triangle index lo*6 - lo(lo-1)/2 + (hi - lo) of
+    // rows 0..5, five bits each, one constant per column (a shift and a mask per lane instead
+    // of the index arithmetic)
+    constexpr auto tri = [](int r, int c) { const int lo = r < c ? r : c, hi = r < c ? c : r;
+                                            return lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo); };
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        const int lo = rr6 < c ? rr6 : c, hi = rr6 < c ? c : rr6;
-        m[c] = __shfl(stat, lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo), 64);
+        const unsigned packed = (unsigned)tri(0, c) | (unsigned)tri(1, c) << 5 | (unsigned)tri(2, c) << 10 |
+                                (unsigned)tri(3, c) << 15 | (unsigned)tri(4, c) << 20 | (unsigned)tri(5, c) << 25;
+        m[c] = __shfl(stat, (int)((packed >> (5 * rr6)) & 31u), 64);
     }
     double rhs = __shfl(stat, 21 + rr6, 64);
 
