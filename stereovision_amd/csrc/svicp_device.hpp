@@ -471,6 +471,26 @@ __device__ __forceinline__ double block_sum_30(double (&acc)[30], double (*red)[
     return s;
 }
 
+// The lower bound `lb` on a point's distance to every other target point after the point
+// has moved by sqrt(m2): a float not above lb - |move| (triangle inequality).  The bound is
+// carried from iteration to iteration, so what is given away here adds up: a factor
+// (1 - 1e-6) per iteration wears a bound down by eight units in the last place each time,
+// and a point whose two nearest target points differ by a few parts in 10^5 would fail its
+// proof, and be searched again, every few iterations.  Instead: d is not below the true
+// move (1e-6 covers the roundings of the three squares, their sum and the root); r = fl(lb - d)
+// lies within half a unit of lb - d, and lb - r is exact when the two are within a factor of
+// two of each other, so comparing it with d tells on which side; only if r came out above
+// does it go down, by one unit.  (A move of more than a quarter of the bound takes the
+// factor as before: nothing is carried far from there.)
+__device__ __forceinline__ float bound_after_move(float lb, float m2)
+{
+    const float d = sqrtf(m2) * kSlackUp;
+    const float r = lb - d;
+    if (d > 0.25f * lb) return r * kSlackDown;
+    // r > 0 here; the float below it
+    return (lb - r >= d) ? r : __uint_as_float(__float_as_uint(r) - 1u);
+}
+
 // Search bounds shared by the two iteration kernels.
 struct CohParams {
     float thr;        // squared-distance threshold of the weight function
@@ -1080,7 +1100,7 @@ __device__ __forceinline__ void iterate_tile(
             for (int sl = 0; sl < NP; ++sl) {
                 const unsigned li = sl * kItThreads + threadIdx.x;
                 float lbn = lb[sl];
-                if (m2[sl] > 0.f) lbn = (lbn - sqrtf(m2[sl]) * kSlackUp) * kSlackDown;
+                if (m2[sl] > 0.f) lbn = bound_after_move(lbn, m2[sl]);
                 const bool has = tp[sl].x == tp[sl].x;          // a neighbour is remembered
                 float dx = px[sl] - tp[sl].x, dy = py[sl] - tp[sl].y, dz = pz[sl] - tp[sl].z;
                 float d2 = __fmul_rn(dx, dx);
