@@ -660,6 +660,9 @@ def main():
                 "value": (time.perf_counter() - t0) * 1e3, "unit": "ms", "cores": 1, "kind": "port",
                 "sample": "the same 1920 x 1080 maps (the inverse projection formed once, not per "
                           "pixel as the reference does)"}
+        return neighbours
+    if rank == 0 and args.extras:
+        neighbours = guard("neighbouring_rows", leg_extras)
 
     # ---- CPU baseline: the oracle on the same pair, one thread ------------
     current[0] = "cpu_baseline"
