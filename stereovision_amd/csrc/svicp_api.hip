@@ -81,13 +81,13 @@ struct DevBuf {
 // staging.  A context owns one; the members of an arena batch share their batch's, so on them
 // only what the iteration loop needs outlives the set-up calls.
 struct Scratch {
-    DevBuf tgt_aos, nrm_aos, run2, end1;
+    DevBuf tgt_aos, nrm_aos, run2, end1, qrun;
     DevBuf tmp_aos, keys_a, keys_b, vals_a, vals_b, marks, ranks, block_of_rank, sort_tmp, bbox6;
     DevBuf knn_idx, knn_d2, unresolved, n_unres;
     float *h_small = nullptr;      // pinned: small results on their way back (bounding box, counts)
     void release()
     {
-        DevBuf *bufs[] = { &tgt_aos, &nrm_aos, &run2, &end1, &tmp_aos, &keys_a, &keys_b, &vals_a, &vals_b,
+        DevBuf *bufs[] = { &tgt_aos, &nrm_aos, &run2, &end1, &qrun, &tmp_aos, &keys_a, &keys_b, &vals_a, &vals_b,
                            &marks, &ranks, &block_of_rank, &sort_tmp, &bbox6, &knn_idx, &knn_d2,
                            &unresolved, &n_unres };
         for (DevBuf *b : bufs) b->release();
@@ -872,7 +872,7 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
                            ctx->scr->tgt_aos.as<float>(), (int)m, ctx->scr->keys_a.as<unsigned long long>(),
                            ctx->scr->vals_a.as<int>());
         LAUNCHCHK("cell_key_kernel");
-        unsigned long long ncell = (unsigned long long)g.nx * g.ny * g.nz;
+        unsigned long long ncell = (unsigned long long)g.nx * g.ny * g.nz * kFineX;     // (the keys carry the quarter cell)
         int bits = 1;
         while (bits < 64 && (ncell >> bits)) ++bits;
         int rc = sort_pairs(ctx, m, bits);
@@ -906,7 +906,8 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
     LAUNCHCHK("finish_dir_kernel");
     HIPCHK(ctx->scr->run2.reserve(sizeof(uint2) * 64 * std::max(nranked, 1)));
     HIPCHK(ctx->scr->end1.reserve(sizeof(unsigned) * 64 * std::max(nranked, 1)));
-    HIPCHK(ctx->quad.reserve(sizeof(uint4) * 2 * 64 * std::max(nranked, 1)));
+    HIPCHK(ctx->quad.reserve(sizeof(uint4) * 2 * 64 * kFineX * std::max(nranked, 1)));
+    HIPCHK(ctx->scr->qrun.reserve(sizeof(uint2) * 64 * kFineX * std::max(nranked, 1)));
     if (nranked > 0) {
         hipLaunchKernelGGL(fill_cells_kernel, dim3(cdiv((long long)nranked * 64, 256)), dim3(256), 0,
                            ctx->stream, g, ctx->scr->keys_b.as<unsigned long long>(), (int)m,
@@ -914,9 +915,14 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
                            ctx->scr->end1.as<unsigned>());
         LAUNCHCHK("fill_cells_kernel");
         g.dir = ctx->dir.as<int>();
-        hipLaunchKernelGGL(fill_quads_kernel, dim3(cdiv((long long)nranked * 64, 256)), dim3(256), 0,
+        hipLaunchKernelGGL(fill_quarter_runs_kernel, dim3(cdiv((long long)nranked * 64 * kFineX, 256)), dim3(256), 0,
+                           ctx->stream, g, ctx->scr->keys_b.as<unsigned long long>(), (int)m,
+                           ctx->scr->block_of_rank.as<int>(), nranked, ctx->scr->run2.as<uint2>(),
+                           ctx->scr->qrun.as<uint2>());
+        LAUNCHCHK("fill_quarter_runs_kernel");
+        hipLaunchKernelGGL(fill_quads_kernel, dim3(cdiv((long long)nranked * 64 * kFineX, 256)), dim3(256), 0,
                            ctx->stream, g, ctx->scr->block_of_rank.as<int>(), nranked,
-                           ctx->scr->run2.as<uint2>(), ctx->quad.as<uint4>());
+                           ctx->scr->qrun.as<uint2>(), ctx->quad.as<uint4>());
         LAUNCHCHK("fill_quads_kernel");
     }
     g.dir = ctx->dir.as<int>();
