@@ -1037,6 +1037,9 @@ __device__ __forceinline__ void iterate_tile(
                 const unsigned pt = min((unsigned)(sl * kItThreads + (line < 16 ? 8 * (line & 7) : 32 * (line - 16))),
                                         (unsigned)(tile_n - 1));
                 touched = line < 8 ? btp[pt].x : line < 16 ? bnv[pt].x : blb[pt];
+            } else if (u < NP * 18 + 2) {
+                // and the two lines of the tile's old sums, which the end of the block asks for
+                touched = (float)partials[(size_t)tile * kNumSums + 16 * (u - NP * 18)];
             }
         }
         __syncthreads();
@@ -1236,10 +1239,11 @@ __device__ __forceinline__ void iterate_tile(
     double old_row = 0.0;
     int exponent = 0;
     if (threadIdx.x < 30) exponent = fx[threadIdx.x];
-    if (APPLY && threadIdx.x < 30) old_row = partials[(size_t)threadIdx.x * nb + tile];
+    // (a tile's 32 sums lie together: one request of two lines)
+    if (APPLY && threadIdx.x < 30) old_row = partials[(size_t)tile * kNumSums + threadIdx.x];
     const double s = block_sum_30(acc, red);
     if (threadIdx.x < 30) {
-        partials[(size_t)threadIdx.x * nb + tile] = s;
+        partials[(size_t)tile * kNumSums + threadIdx.x] = s;
         // both rows go to fixed point before they are subtracted: the totals are then the exact
         // integer sum of the tiles' current rows, whatever the order of the additions
         const fx_t d = to_fixed(s, exponent) - to_fixed(old_row, exponent);
