@@ -1238,7 +1238,8 @@ __device__ __forceinline__ void iterate_tile(
     // for them, and the block sum covers their latency
     double old_row = 0.0;
     int exponent = 0;
-    if (threadIdx.x < 30) exponent = fx[threadIdx.x];
+    // (the threads that need the scaling are the lanes that asked for it with the sums)
+    if (threadIdx.x < 30) exponent = (APPLY && solve_now) ? sums.exponent : fx[threadIdx.x];
     // (a tile's 32 sums lie together: one request of two lines)
     if (APPLY && threadIdx.x < 30) old_row = partials[(size_t)tile * kNumSums + threadIdx.x];
     const double s = block_sum_30(acc, red);
