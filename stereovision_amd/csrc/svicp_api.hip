@@ -162,7 +162,7 @@ struct svicp_ctx {
     bool have_target = false;
     GridDesc g{};
     int nranked = 0;
-    DevBuf pts, nrm, dir, quad;
+    DevBuf pts, nrm, dir, quad, g_dev;
     Scratch own_scr, *scr = &own_scr;    // (an arena batch points its members at one shared Scratch)
     bool lean() const { return scr != &own_scr; }
 
@@ -534,11 +534,11 @@ void launch_iteration(svicp_ctx *ctx, int k, const LoopBufs &b)
         if (apart)                                                                                \
             hipLaunchKernelGGL((icp_iterate_kernel<APPLY, CERTIFY, 4, INPLACE, true>), grid, block, 0, ctx->stream, \
                                tot, del, fx, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, \
-                               xh, ih, cp, partials, ctx->g, rt);                                 \
+                               xh, ih, cp, partials, ctx->g_dev.as<GridDesc>(), rt);              \
         else                                                                                      \
             hipLaunchKernelGGL((icp_iterate_kernel<APPLY, CERTIFY, 4, INPLACE, false>), grid, block, 0, ctx->stream, \
                                tot, del, fx, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, \
-                               xh, ih, cp, partials, ctx->g, (const double *)nullptr);            \
+                               xh, ih, cp, partials, ctx->g_dev.as<GridDesc>(), (const double *)nullptr); \
     } while (0)
     // iteration 0 reads the source as set and moves nothing, iteration 1 reads it and writes
     // the moving copy, later ones update the moving copy where it is
@@ -724,7 +724,7 @@ int svicp_destroy(svicp_ctx *ctx)
     drop_graph(ctx);
     if (ctx->comm) { (void)rccl_api()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
-    DevBuf *bufs[] = { &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->quad, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx,
+    DevBuf *bufs[] = { &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->quad, &ctx->g_dev, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx,
                        &ctx->wy, &ctx->wz, &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->tile_flags, &ctx->perm,
                        &ctx->partials, &ctx->totals, &ctx->deltas, &ctx->state, &ctx->xhist, &ctx->ihist,
                        &ctx->p2p_sums, &ctx->rthist, &ctx->fx_exp, &ctx->rt_apart };
@@ -932,6 +932,9 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
     g.pts = ctx->pts.as<float4>();
     g.nrm = ctx->nrm.as<float>();
     ctx->g = g;
+    // the iteration kernel reads the description from device memory
+    HIPCHK(ctx->g_dev.reserve(sizeof(GridDesc)));
+    HIPCHK(hipMemcpyAsync(ctx->g_dev.p, &ctx->g, sizeof(GridDesc), hipMemcpyHostToDevice, ctx->stream));
 
     if (m > 0) {
         hipLaunchKernelGGL(gather_target_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream,
@@ -1822,7 +1825,7 @@ int svicp_batch_create_from_arrays(int device_id, int count, const int64_t *tgt_
         }
         if (opt) c->opt = *opt; else svicp_default_options(&c->opt);
         c->scr = &b->shared;
-        DevBuf *persistent[] = { &c->pts, &c->nrm, &c->dir, &c->quad, &c->sx0, &c->sy0, &c->sz0, &c->wx, &c->wy,
+        DevBuf *persistent[] = { &c->pts, &c->nrm, &c->dir, &c->quad, &c->g_dev, &c->sx0, &c->sy0, &c->sz0, &c->wx, &c->wy,
                                  &c->wz, &c->st_tp, &c->st_nv, &c->st_lb, &c->tile_flags, &c->perm, &c->partials,
                                  &c->totals, &c->deltas, &c->state, &c->xhist, &c->ihist, &c->p2p_sums,
                                  &c->rthist, &c->fx_exp, &c->rt_apart };

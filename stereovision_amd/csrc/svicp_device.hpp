@@ -1275,8 +1275,12 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     unsigned long long *ps_active, Float3 *ps_tp, Float3 *ps_nv, float *ps_lb,   // a PointState, member by member
     const float *sx_in, const float *sy_in, const float *sz_in, float *sx_out, float *sy_out,
     float *sz_out, IcpState *st, double *X_hist, double *info_hist, CohParams cp,
-    double *__restrict__ partials, GridDesc g, const double *__restrict__ rt_given)
+    double *__restrict__ partials, const GridDesc *__restrict__ grid, const double *__restrict__ rt_given)
 {
+    // The target's grid is described in device memory, not in the kernel's arguments: only the
+    // search reads it (scalar loads where it needs them), and thirty words fewer have to be
+    // fetched, and parked in spare register lanes, before a launch's first loads can go out.
+    const GridDesc &g = *grid;
     const int nb = (int)gridDim.x;
     PointState ps;
     ps.tp = ps_tp; ps.nv = ps_nv; ps.lb = ps_lb; ps.active = ps_active;
