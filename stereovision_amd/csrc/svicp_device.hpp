@@ -1014,7 +1014,13 @@ __device__ __forceinline__ void iterate_tile(
         // totals[k]: sums after iteration k - 1 (row 0 is zero); deltas[k]: changes made by iteration k
         if (wv == 0) {
             solve_and_update(sums, totals + (size_t)iter * kNumSums, st, X_hist, info_hist, iter - 1,
-                             tile == 0, shRT
+                             // Every block solves the same system; ONE records the result.  The
+                             // launch's last block does: once a registration has settled it holds a
+                             // tile without work (choose_tile gives the first blocks to the tiles
+                             // with work), so the record's trip to memory for the accumulated
+                             // transform delays nobody -- in the block of tile 0, which usually has
+                             // work, it ended the launch whenever no tile had to search.
+                             blockIdx.x + 1 == gridDim.x, shRT
 #ifdef SVICP_TRACE
                              , (iter < kTraceIters && tile < kTraceTiles)
                                    ? g_trace + ((size_t)iter * kTraceTiles + tile) * kTraceStamps : nullptr

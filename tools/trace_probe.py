@@ -116,3 +116,13 @@ for k in range(1, 8):
     ph = t[act][:, 1:8] - t0
     print(f"  {k}: {np.median(t[:, 0] - t0):5.2f} | " + " ".join(f"{np.median(sv_[:, j]):5.2f}" for j in range(5)) + " | " +
           " ".join(f"{np.median(ph[:, j]):5.2f}" for j in range(7)))
+
+# the block that records (tile 0) against the other active tiles, and which tile ends a launch
+for k in (17, 25, 29):
+    t = tr[k]
+    t0 = t[:, 0][t[:, 0] > 0].min()
+    active = np.where(t[:, 7] > 0)[0]
+    last = np.where(t > 0, t, 0).max(axis=1)
+    others = [a for a in active if a != 0]
+    print(f"iteration {k}: launch ends with tile {int(last.argmax())}; tile 0 (records): solved {t[0,1]-t0:.2f} end {t[0,7]-t0:.2f}; "
+          f"other active tiles: solved median {np.median(t[others,1]-t0):.2f} end median {np.median(t[others,7]-t0):.2f} max {np.max(t[others,7]-t0):.2f}")
