@@ -301,9 +301,12 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ((traffic_settled / (settled_ms * 1e-3) / 1e9) / HBM_PEAK_GBS) if traffic_settled else None,
                 "launches_of_this_regime_per_step": int(settled.sum()),
-                "where_the_time_goes_us": {"kernel boundary": 2.7, "redundant solve": 1.6,
-                                           "tiles that still have work": 3.5,
-                                           "source": "per-block wall-clock stamps of a build with -DSVICP_TRACE (tools/trace_probe.py)"},
+                "where_the_time_goes_us": {"between launches": 1.4, "until a launch's first loads are back": 1.3,
+                                           "redundant solve": 1.5, "update and all-points-still test": 0.7,
+                                           "tiles that still have work (re-prove, re-accumulate, block sums)": 3.2,
+                                           "search of a near-tie point (17 of 25 settled launches of a step)": 1.8,
+                                           "source": "per-block wall-clock stamps of a build with -DSVICP_TRACE "
+                                                     "(tools/trace_probe.py); the stamps add about 0.1 us each"},
             },
             # the standalone correspondence kernel (the reduction has no kernel of its own: it is
             # fused into icp_iterate_kernel)
