@@ -279,7 +279,11 @@ __device__ __forceinline__ void nn_capped_wave(const GridDesc &g, float qx, floa
     for (unsigned f = lane; f < T; f += 64) {
         const unsigned j = f + (f < P1 ? o0 : f < P2 ? o1 : f < P3 ? o2 : o3);
         const float4 p = g.pts[j];
+        // every candidate's normal is touched in the same trip: the caller's gather of the
+        // winner's normal then finds its line in the cache instead of making a trip of its own
+        const float touched_normal = g.nrm[3 * (size_t)j];
         const float d = dist2(qx, qy, qz, p);
+        asm volatile("" ::"v"(touched_normal));
         const unsigned long long key =
             ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(p.w);
         if (key < bkey) { bkey = key; mp = p; mpos = (int)j; }
