@@ -365,6 +365,15 @@ int svicp_time_gather(svicp_ctx *ctx, int real_addresses, int per_query, int rep
 /* Sizes of the resident clouds. */
 int svicp_sizes(const svicp_ctx *ctx, int64_t *m, int64_t *n);
 
+/* The target's search tables (no counterpart in the reference, whose index is FLANN's
+ * kd-tree, CKNNSearch.cpp:27-35): blocks of 4 x 4 x 4 cells that have a rank, bytes of the
+ * probe records (16 bytes per quarter cell of a ranked block), and how many of the records
+ * are kept in full (32 bytes more each) because they do not fit the packed form -- a run of
+ * more than 254 points, or rows of cells next to each other more than 65535 points apart in
+ * the sorted target.  Any pointer may be NULL. */
+int svicp_grid_info(const svicp_ctx *ctx, int64_t *ranked_blocks, int64_t *record_bytes,
+                    int64_t *records_in_full);
+
 #ifdef __cplusplus
 }
 #endif

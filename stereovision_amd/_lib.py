@@ -85,6 +85,7 @@ SYMBOLS = {
     "svicp_time_nn": (C.c_int, [_ctx, C.c_int, C.c_int, _dp]),
     "svicp_time_gather": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "svicp_sizes": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "svicp_grid_info": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "svicp_search_counts": (C.c_int, [_ctx, C.c_int, _dp]),
     "svicp_run_point2point": (C.c_int, [_ctx, C.c_int, _dp, C.POINTER(Info)]),
     "svicp_get_history_rt": (C.c_int, [_ctx, C.c_int, _dp, _dp]),

@@ -81,13 +81,13 @@ struct DevBuf {
 // staging.  A context owns one; the members of an arena batch share their batch's, so on them
 // only what the iteration loop needs outlives the set-up calls.
 struct Scratch {
-    DevBuf tgt_aos, nrm_aos, run2, end1, qrun;
+    DevBuf tgt_aos, nrm_aos, run2, end1, qrun, big_count;
     DevBuf tmp_aos, keys_a, keys_b, vals_a, vals_b, marks, ranks, block_of_rank, sort_tmp, bbox6;
     DevBuf knn_idx, knn_d2, unresolved, n_unres;
     float *h_small = nullptr;      // pinned: small results on their way back (bounding box, counts)
     void release()
     {
-        DevBuf *bufs[] = { &tgt_aos, &nrm_aos, &run2, &end1, &qrun, &tmp_aos, &keys_a, &keys_b, &vals_a, &vals_b,
+        DevBuf *bufs[] = { &tgt_aos, &nrm_aos, &run2, &end1, &qrun, &big_count, &tmp_aos, &keys_a, &keys_b, &vals_a, &vals_b,
                            &marks, &ranks, &block_of_rank, &sort_tmp, &bbox6, &knn_idx, &knn_d2,
                            &unresolved, &n_unres };
         for (DevBuf *b : bufs) b->release();
@@ -162,7 +162,8 @@ struct svicp_ctx {
     bool have_target = false;
     GridDesc g{};
     int nranked = 0;
-    DevBuf pts, nrm, dir, quad, g_dev;
+    int quad_big_records = 0;      // probe records kept in full (they do not fit the packed form)
+    DevBuf pts, nrm, dir, quad, quad_big, g_dev;
     Scratch own_scr, *scr = &own_scr;    // (an arena batch points its members at one shared Scratch)
     bool lean() const { return scr != &own_scr; }
 
@@ -724,7 +725,7 @@ int svicp_destroy(svicp_ctx *ctx)
     drop_graph(ctx);
     if (ctx->comm) { (void)rccl_api()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
-    DevBuf *bufs[] = { &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->quad, &ctx->g_dev, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx,
+    DevBuf *bufs[] = { &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->quad, &ctx->quad_big, &ctx->g_dev, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx,
                        &ctx->wy, &ctx->wz, &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->tile_flags, &ctx->perm,
                        &ctx->partials, &ctx->totals, &ctx->deltas, &ctx->state, &ctx->xhist, &ctx->ihist,
                        &ctx->p2p_sums, &ctx->rthist, &ctx->fx_exp, &ctx->rt_apart };
@@ -755,6 +756,18 @@ int svicp_get_options(const svicp_ctx *ctx, svicp_options *opt)
 {
     if (!ctx || !opt) return SVICP_ERR_ARG;
     *opt = ctx->opt;
+    return SVICP_OK;
+}
+
+int svicp_grid_info(const svicp_ctx *ctx, int64_t *ranked_blocks, int64_t *record_bytes,
+                    int64_t *records_in_full)
+{
+    if (!ctx || !ctx->have_target) return SVICP_ERR_ARG;
+    if (ranked_blocks) *ranked_blocks = ctx->nranked;
+    if (record_bytes)
+        *record_bytes = (int64_t)sizeof(uint4) * 64 * kFineX * std::max(ctx->nranked, 1) +
+                        (int64_t)sizeof(uint4) * 2 * ctx->quad_big_records;
+    if (records_in_full) *records_in_full = ctx->quad_big_records;
     return SVICP_OK;
 }
 
@@ -906,7 +919,8 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
     LAUNCHCHK("finish_dir_kernel");
     HIPCHK(ctx->scr->run2.reserve(sizeof(uint2) * 64 * std::max(nranked, 1)));
     HIPCHK(ctx->scr->end1.reserve(sizeof(unsigned) * 64 * std::max(nranked, 1)));
-    HIPCHK(ctx->quad.reserve(sizeof(uint4) * 2 * 64 * kFineX * std::max(nranked, 1)));
+    HIPCHK(ctx->quad.reserve(sizeof(uint4) * 64 * kFineX * std::max(nranked, 1)));
+    HIPCHK(ctx->scr->big_count.reserve(sizeof(int)));
     HIPCHK(ctx->scr->qrun.reserve(sizeof(uint2) * 64 * kFineX * std::max(nranked, 1)));
     if (nranked > 0) {
         hipLaunchKernelGGL(fill_cells_kernel, dim3(cdiv((long long)nranked * 64, 256)), dim3(256), 0,
@@ -920,15 +934,35 @@ int svicp_set_target(svicp_ctx *ctx, const float *xyz_aos, int64_t m, const floa
                            ctx->scr->block_of_rank.as<int>(), nranked, ctx->scr->run2.as<uint2>(),
                            ctx->scr->qrun.as<uint2>());
         LAUNCHCHK("fill_quarter_runs_kernel");
-        hipLaunchKernelGGL(fill_quads_kernel, dim3(cdiv((long long)nranked * 64 * kFineX, 256)), dim3(256), 0,
-                           ctx->stream, g, ctx->scr->block_of_rank.as<int>(), nranked,
-                           ctx->scr->qrun.as<uint2>(), ctx->quad.as<uint4>());
-        LAUNCHCHK("fill_quads_kernel");
+        // the packed probe records; the few that do not fit the packing go to quad_big, whose
+        // size is known only once they have been counted: a second pass when the first found
+        // more than the buffer holds (none at all for a cloud without piles of duplicates or
+        // rows of more than 65535 points)
+        for (int pass = 0; pass < 2; ++pass) {
+            const int capacity = (int)std::min<size_t>(ctx->quad_big.cap / (2 * sizeof(uint4)), 0x7fffffff);
+            HIPCHK(hipMemsetAsync(ctx->scr->big_count.p, 0, sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(fill_quads_kernel, dim3(cdiv((long long)nranked * 64 * kFineX, 256)), dim3(256), 0,
+                               ctx->stream, g, ctx->scr->block_of_rank.as<int>(), nranked,
+                               ctx->scr->qrun.as<uint2>(), ctx->quad.as<uint4>(), ctx->quad_big.as<uint4>(),
+                               capacity, ctx->scr->big_count.as<int>());
+            LAUNCHCHK("fill_quads_kernel");
+            int *count = reinterpret_cast<int *>(ctx->scr->h_small);
+            HIPCHK(hipMemcpyAsync(count, ctx->scr->big_count.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            ctx->quad_big_records = *count;
+            if (*count <= capacity) break;
+            if (pass == 1) return fail(ctx, SVICP_ERR_HIP, "svicp_set_target: the probe records changed between two passes");
+            HIPCHK(ctx->quad_big.reserve(sizeof(uint4) * 2 * (size_t)*count));
+        }
+    } else {
+        // no ranked block: probes read record 0 and drop it, so it must be a plain record
+        HIPCHK(hipMemsetAsync(ctx->quad.p, 0, sizeof(uint4), ctx->stream));
     }
     g.dir = ctx->dir.as<int>();
     g.run2 = ctx->scr->run2.as<uint2>();
     g.end1 = ctx->scr->end1.as<unsigned>();
     g.quad = ctx->quad.as<uint4>();
+    g.quad_big = ctx->quad_big.as<uint4>();
     g.pts = ctx->pts.as<float4>();
     g.nrm = ctx->nrm.as<float>();
     ctx->g = g;
@@ -1825,7 +1859,7 @@ int svicp_batch_create_from_arrays(int device_id, int count, const int64_t *tgt_
         }
         if (opt) c->opt = *opt; else svicp_default_options(&c->opt);
         c->scr = &b->shared;
-        DevBuf *persistent[] = { &c->pts, &c->nrm, &c->dir, &c->quad, &c->g_dev, &c->sx0, &c->sy0, &c->sz0, &c->wx, &c->wy,
+        DevBuf *persistent[] = { &c->pts, &c->nrm, &c->dir, &c->quad, &c->quad_big, &c->g_dev, &c->sx0, &c->sy0, &c->sz0, &c->wx, &c->wy,
                                  &c->wz, &c->st_tp, &c->st_nv, &c->st_lb, &c->tile_flags, &c->perm, &c->partials,
                                  &c->totals, &c->deltas, &c->state, &c->xhist, &c->ihist, &c->p2p_sums,
                                  &c->rthist, &c->fx_exp, &c->rt_apart };

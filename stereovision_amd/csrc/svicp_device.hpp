@@ -8,11 +8,12 @@
 //              4x4x4 blocks; `dir` maps a block to its rank among the blocks
 //              that hold (or precede in x) a point, -1 otherwise.  Per ranked
 //              block 64 entries: run2 = {first point of the cell, end of the
-//              NEXT cell in x} and end1 = end of the cell itself; quad = the run2
-//              of the cell and of its neighbours in y, in z and in both, the
-//              four runs of a 2x2x2 probe that starts at the cell, in two
-//              16-byte words (one table look-up and two loads per probe instead
-//              of four and four).
+//              NEXT cell in x} and end1 = end of the cell itself; quad = per
+//              quarter cell the four runs a probe that starts there walks (its
+//              own row of cells and the rows next to it in y, in z and in
+//              both), packed in ONE 16-byte word (one table look-up and one
+//              load per probe instead of four and four); the rare record that
+//              does not fit the packing is kept in full in quad_big.
 //   source   : SoA x[], y[], z[] in Morton order (perm[] maps back).
 //
 // A query probes the 2x2x2 cells that cover its search cube: four 2-cell runs.
@@ -74,8 +75,9 @@ struct GridDesc {
     const int *dir;          // [nbz][nby][nbx]
     const uint2 *run2;       // [ranked blocks * 64]
     const unsigned *end1;    // [ranked blocks * 64]
-    const uint4 *quad;       // [ranked blocks * 256][2]: the four runs a probe walks, one record per
-                             // QUARTER cell in x (kFineX per cell): see probe_origin
+    const uint4 *quad;       // [ranked blocks * 256]: the four runs a probe walks, one packed record per
+                             // QUARTER cell in x (kFineX per cell): see probe_origin, probe_runs
+    const uint4 *quad_big;   // [slots][2]: the records that do not fit the packing, in full
     const float4 *pts;       // [m] sorted
     const float *nrm;        // [3 m] sorted
 };
@@ -149,6 +151,33 @@ __device__ __forceinline__ bool probe_origin(const GridDesc &g, float qx, float 
 __device__ __forceinline__ int quarter_local(int cxq, int cy, int cz)
 {
     return ((cz & 3) << 6) | ((cy & 3) << 4) | (cxq & (4 * kFineX - 1));
+}
+
+// A probe record: the four runs {start, end} a probe from one quarter cell walks, run r in
+// the row of cells (cy + (r & 1), cz + (r >> 1)).  Packed in 16 bytes: x = start of run 0,
+// y = start of run 2, z = (start of run 1 - start of run 0) | (start of run 3 - start of
+// run 2) << 16, w = the four lengths, a byte each.  (Rows next to each other in y follow
+// each other in the sorted target, so the differences are small; an empty run is given its
+// partner's start.  Half the bytes of eight plain words: a launch that searches every point
+// moves a third of its bytes for these records, and it runs at the speed of its bytes.)  A
+// record with a length above 254 or a difference above 65535 -- duplicates piled up in a cell,
+// rows of more than 65535 points -- has w = kQuadBig and in x its slot in quad_big, where it
+// is kept as eight plain words.
+constexpr unsigned kQuadBig = 0xffffffffu;
+__device__ __forceinline__ void probe_runs(const GridDesc &g, size_t e, uint2 (&run)[4])
+{
+    const uint4 c = g.quad[e];
+    if (__builtin_expect(c.w == kQuadBig, 0)) {
+        const uint4 a = g.quad_big[2 * (size_t)c.x], b = g.quad_big[2 * (size_t)c.x + 1];
+        run[0] = make_uint2(a.x, a.y); run[1] = make_uint2(a.z, a.w);
+        run[2] = make_uint2(b.x, b.y); run[3] = make_uint2(b.z, b.w);
+        return;
+    }
+    const unsigned s1 = c.x + (c.z & 0xffffu), s3 = c.y + (c.z >> 16);
+    run[0] = make_uint2(c.x, c.x + (c.w & 0xffu));
+    run[1] = make_uint2(s1, s1 + ((c.w >> 8) & 0xffu));
+    run[2] = make_uint2(c.y, c.y + ((c.w >> 16) & 0xffu));
+    run[3] = make_uint2(s3, s3 + (c.w >> 24));
 }
 
 // Walks four runs of candidates as one flat list, CH at a time.  `fetch(j)` returns point j
@@ -234,9 +263,8 @@ __device__ __forceinline__ void nn_capped(const GridDesc &g, float qx, float qy,
     const int rank = g.dir[dir_index(g, cx, cy, cz)];
     // an unranked block has no entry: read entry 0 of the table and drop it
     const size_t e = rank >= 0 ? (size_t)rank * (64 * kFineX) + quarter_local(cxq, cy, cz) : 0;
-    const uint4 a = g.quad[2 * e], b = g.quad[2 * e + 1];
-    uint2 run[4] = { make_uint2(a.x, a.y), make_uint2(a.z, a.w), make_uint2(b.x, b.y),
-                     make_uint2(b.z, b.w) };
+    uint2 run[4];
+    probe_runs(g, e, run);
     if (rank < 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) run[r] = make_uint2(0u, 0u);
@@ -264,9 +292,8 @@ __device__ __forceinline__ void nn_capped_wave(const GridDesc &g, float qx, floa
     const int rank = g.dir[dir_index(g, cx, cy, cz)];       // the same address in every lane
     if (rank < 0) return;
     const size_t e = (size_t)rank * (64 * kFineX) + quarter_local(cxq, cy, cz);
-    const uint4 a = g.quad[2 * e], b = g.quad[2 * e + 1];
-    const uint2 run[4] = { make_uint2(a.x, a.y), make_uint2(a.z, a.w), make_uint2(b.x, b.y),
-                           make_uint2(b.z, b.w) };
+    uint2 run[4];
+    probe_runs(g, e, run);
     const unsigned P1 = run[0].y - run[0].x;
     const unsigned P2 = P1 + (run[1].y - run[1].x);
     const unsigned P3 = P2 + (run[2].y - run[2].x);
@@ -1551,8 +1578,8 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
 // ------------------------------------------------------------------------
 // Gather probe (measurement only): the vector-memory instruction stream of the capped
 // search with nothing else around it, to see what the texture-address path of this GPU
-// delivers for it.  REAL: every query makes the same table look-ups (directory, the two
-// words of its probe record) and loads exactly the candidates nn_capped would, four at a
+// delivers for it.  REAL: every query makes the same table look-ups (directory, its
+// probe record) and loads exactly the candidates nn_capped would, four at a
 // time as the search does, no distance arithmetic, no running best, nothing written per query.  !REAL:
 // `per_query` 16-byte loads per lane from hashed places of the sorted target (no look-ups,
 // no locality between lanes), eight in flight.  With `instr` non-null every wave adds the
@@ -1585,13 +1612,13 @@ __global__ __launch_bounds__(kBlockThreads) void gather_probe_kernel(
             if (live && probe_origin(g, qx, qy, qz, cx, cy, cz, &cxq)) {
                 const int rank = g.dir[dir_index(g, cx, cy, cz)];
                 const size_t e = rank >= 0 ? (size_t)rank * (64 * kFineX) + quarter_local(cxq, cy, cz) : 0;
-                const uint4 a = g.quad[2 * e], b = g.quad[2 * e + 1];
+                uint2 got[4];
+                probe_runs(g, e, got);
                 if (rank >= 0) {
-                    run[0] = make_uint2(a.x, a.y); run[1] = make_uint2(a.z, a.w);
-                    run[2] = make_uint2(b.x, b.y); run[3] = make_uint2(b.z, b.w);
+                    run[0] = got[0]; run[1] = got[1]; run[2] = got[2]; run[3] = got[3];
                 }
             }
-            issued += 3;
+            issued += 2;
             P1 = run[0].y - run[0].x;
             P2 = P1 + (run[1].y - run[1].x);
             P3 = P2 + (run[2].y - run[2].x);
@@ -2341,7 +2368,8 @@ __global__ void fill_quarter_runs_kernel(GridDesc g, const unsigned long long *_
 // those of the same quarter in the rows next to it in y, in z and in both.  A row outside the
 // grid or in an unranked block (no point in its run) gives an empty run.
 __global__ void fill_quads_kernel(GridDesc g, const int *__restrict__ block_of_rank, int nranked,
-                                  const uint2 *__restrict__ qrun, uint4 *__restrict__ quad)
+                                  const uint2 *__restrict__ qrun, uint4 *__restrict__ quad,
+                                  uint4 *__restrict__ quad_big, int big_capacity, int *__restrict__ big_count)
 {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)nranked * 64 * kFineX) return;
@@ -2358,8 +2386,26 @@ __global__ void fill_quads_kernel(GridDesc g, const int *__restrict__ block_of_r
             if (nrank >= 0) nb[r] = qrun[(long long)nrank * (64 * kFineX) + quarter_local(cxq, y, z)];
         }
     }
-    quad[2 * t] = make_uint4(nb[0].x, nb[0].y, nb[1].x, nb[1].y);
-    quad[2 * t + 1] = make_uint4(nb[2].x, nb[2].y, nb[3].x, nb[3].y);
+    // the packed form (probe_runs): an empty run takes its partner's start, so the difference
+    // of the starts is that of two rows next to each other in y, or zero
+    const unsigned l0 = nb[0].y - nb[0].x, l1 = nb[1].y - nb[1].x, l2 = nb[2].y - nb[2].x,
+                   l3 = nb[3].y - nb[3].x;
+    const unsigned s0 = l0 ? nb[0].x : nb[1].x, s1 = l1 ? nb[1].x : s0;
+    const unsigned s2 = l2 ? nb[2].x : nb[3].x, s3 = l3 ? nb[3].x : s2;
+    const bool fits = s1 >= s0 && s3 >= s2 && s1 - s0 <= 0xffffu && s3 - s2 <= 0xffffu && l0 <= 254u &&
+                      l1 <= 254u && l2 <= 254u && l3 <= 254u;
+    if (fits) {
+        quad[t] = make_uint4(s0, s2, (s1 - s0) | ((s3 - s2) << 16), l0 | (l1 << 8) | (l2 << 16) | (l3 << 24));
+    } else {
+        // (which record gets which slot depends on the order of arrival; the slot is looked
+        // at by nobody but probe_runs)
+        const int slot = atomicAdd(big_count, 1);
+        if (slot < big_capacity) {
+            quad_big[2 * (size_t)slot] = make_uint4(nb[0].x, nb[0].y, nb[1].x, nb[1].y);
+            quad_big[2 * (size_t)slot + 1] = make_uint4(nb[2].x, nb[2].y, nb[3].x, nb[3].y);
+        }
+        quad[t] = make_uint4((unsigned)slot, 0u, 0u, kQuadBig);
+    }
 }
 
 __global__ void gather_target_kernel(const float *__restrict__ aos, const float *__restrict__ nrm_aos,

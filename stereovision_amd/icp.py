@@ -173,6 +173,13 @@ class Context:
         self._check(self._lib.svicp_sizes(self._h, C.byref(m), C.byref(n)))
         return m.value, n.value
 
+    def grid_info(self):
+        """(ranked blocks, bytes of the probe records, records kept in full) of the target's
+        search tables."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.svicp_grid_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     # -- registration --
     def run(self, iterations):
         """Returns (4x4 transform, Info)."""

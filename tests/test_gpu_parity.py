@@ -507,6 +507,47 @@ def test_exact_and_capped_search_agree_within_threshold(ctx, po):
     assert ctx.time_nn(exact=True, reps=2) > 0 and ctx.time_nn(exact=False, reps=2) > 0
 
 
+def test_probe_records_that_do_not_fit_the_packed_form(ctx, po):
+    """Probe records are packed in 16 bytes (run lengths in a byte, the distance between the
+    starts of rows next to each other in 16 bits); the records that do not fit are kept in
+    full.  A pile of near-coincident points (runs of more than 254) and two long parallel
+    lines of points one cell apart (rows more than 65535 points apart in the sorted target)
+    make such records; the capped search, the loop and the exact search must answer as the
+    oracle does, with and without them."""
+    rng = np.random.default_rng(23)
+    pile = (np.float32([10, 10, 10]) + rng.random((700, 3)) * 0.05).astype(np.float32)
+    xs = np.linspace(-200.0, 3000.0, 70000)
+    line_a = np.stack([xs, np.full_like(xs, 40.0), np.full_like(xs, 5.0)], 1)
+    # four lines 2.5 apart in y: every row of cells (about 4.5 wide) they cross holds one or two
+    lines = [line_a + [0.013 * k, 2.5 * k, 0.0] for k in range(4)]
+    line_b = lines[3]
+    cloud = (rng.random((3000, 3)) * [60, 60, 20]).astype(np.float32)
+    tgt = np.concatenate([cloud, pile] + lines).astype(np.float32)
+    nrm = np.zeros_like(tgt); nrm[:, 2] = 1
+    ctx.set_target(tgt, nrm)
+    ranked, rec_bytes, in_full = ctx.grid_info()
+    assert in_full > 0 and rec_bytes == 16 * 256 * ranked + 32 * in_full
+    q = np.concatenate([pile[:200] + np.float32(0.3), cloud[:500] + np.float32(0.2),
+                        line_a[::400] + [0.2, 1.9, 0.3], line_b[::400] + [-0.2, -1.7, 0.1],
+                        np.float32([[10.02, 10.02, 10.02], [1400, 42.3, 5], [500, 500, 500]])]).astype(np.float32)
+    ctx.set_source(q)
+    ci, cd = ctx.correspondences()
+    oi, od = po.KDTree(tgt).knn(q, 1)
+    hit = od[:, 0] <= 5.0
+    assert hit.sum() > 800 and (~hit).sum() >= 1
+    assert np.array_equal(ci[hit], oi[hit, 0]) and np.array_equal(cd[hit], od[hit, 0])
+    assert (ci[~hit] == -1).all()
+    ei, ed = ctx.knn(q, 1)
+    assert np.array_equal(ei, oi) and np.array_equal(ed, od)
+    # a second target in the same context without such records: none are counted
+    ctx.set_target(cloud, np.zeros_like(cloud))
+    assert ctx.grid_info()[2] == 0
+    ctx.set_source(cloud[:100] + np.float32(0.1))
+    ci, _ = ctx.correspondences()
+    oi, _ = po.KDTree(cloud).knn(cloud[:100] + np.float32(0.1), 1)
+    assert np.array_equal(ci, oi[:, 0])
+
+
 # ---- batches of independent pairs ---------------------------------------------
 def _batch_pairs():
     """Pairs of different sizes (ragged last tiles, fewer points than one tile) and poses."""
