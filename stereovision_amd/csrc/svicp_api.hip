@@ -124,7 +124,8 @@ constexpr size_t kEnqOffDeltas = kEnqOffTotals + enq_align(sizeof(double) * kNum
 constexpr size_t kEnqOffXhist = kEnqOffDeltas + enq_align(sizeof(double) * kDeltaRow * (kEnqMaxIters + 1));
 constexpr size_t kEnqOffIhist = kEnqOffXhist + enq_align(sizeof(double) * 6 * kEnqMaxIters);
 constexpr size_t kEnqOffFlags = kEnqOffIhist + enq_align(sizeof(double) * 4 * kEnqMaxIters);
-constexpr size_t kEnqOffPartials = kEnqOffFlags + enq_align(sizeof(unsigned long long) * kFlagRows * kFlagWords);
+constexpr size_t kFlagBytes = sizeof(unsigned long long) * kFlagRows * kFlagWords + sizeof(float4) * kFlagCap;   // flag rows, then a look-ahead position per tile
+constexpr size_t kEnqOffPartials = kEnqOffFlags + enq_align(kFlagBytes);
 constexpr size_t kEnqBytes = kEnqOffPartials + enq_align(sizeof(double) * kNumSums * kEnqMaxTiles);
 static __device__ __align__(256) unsigned char scratch[kEnqBytes];   // about 1.2 MB
 
@@ -453,8 +454,11 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
     ctx->nb = nb; ctx->chunk = chunk;
     HIPCHK(ctx->partials.reserve(sizeof(double) * kNumSums * nb));
     if (!ctx->tile_flags.p) {
-        HIPCHK(ctx->tile_flags.reserve(sizeof(unsigned long long) * kFlagRows * kFlagWords));
+        HIPCHK(ctx->tile_flags.reserve(kFlagBytes));
         HIPCHK(hipMemsetAsync(ctx->tile_flags.p, 0, sizeof(unsigned long long) * kFlagRows * kFlagWords, ctx->stream));
+        // (the look-ahead positions behind the rows start as NaN: nothing to look ahead for)
+        HIPCHK(hipMemsetAsync(ctx->tile_flags.as<char>() + sizeof(unsigned long long) * kFlagRows * kFlagWords, 0xff,
+                              sizeof(float4) * kFlagCap, ctx->stream));
     }
     HIPCHK(ctx->state.reserve(sizeof(IcpState)));
     if (iters > ctx->hist_cap) {

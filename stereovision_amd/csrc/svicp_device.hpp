@@ -339,6 +339,32 @@ __device__ __forceinline__ void nn_capped_wave(const GridDesc &g, float qx, floa
     if (SECOND) *second = b2;
 }
 
+// Asks for the lines a search from (qx, qy, qz) -- the same in every lane -- would read, and
+// waits for none of the candidates: the directory word, the probe record, then lane f the
+// f-th candidate and its normal (t0, t1: to be kept alive by the caller until it can afford
+// to wait).  Any position is safe, a stale or never-written one included: the origin test
+// rejects what lies outside the grid (NaN too), and inside it every table entry is valid.
+__device__ __forceinline__ void probe_touch(const GridDesc &g, float qx, float qy, float qz, float &t0,
+                                            float &t1)
+{
+    int cx, cy, cz, cxq;
+    if (!probe_origin(g, qx, qy, qz, cx, cy, cz, &cxq)) return;
+    const int rank = g.dir[dir_index(g, cx, cy, cz)];
+    if (rank < 0) return;
+    uint2 run[4];
+    probe_runs(g, (size_t)rank * (64 * kFineX) + quarter_local(cxq, cy, cz), run);
+    const unsigned P1 = run[0].y - run[0].x;
+    const unsigned P2 = P1 + (run[1].y - run[1].x);
+    const unsigned P3 = P2 + (run[2].y - run[2].x);
+    const unsigned T = P3 + (run[3].y - run[3].x);
+    const unsigned f = threadIdx.x & 63;
+    if (f < T) {
+        const unsigned j = f + (f < P1 ? run[0].x : f < P2 ? run[1].x - P1 : f < P3 ? run[2].x - P2 : run[3].x - P3);
+        t0 = g.pts[j].x;
+        t1 = g.nrm[3 * (size_t)j];
+    }
+}
+
 // Visits every target point in the cell box [x0,x1] x [y0,y1] x [z0,z1]
 // (already clipped to the grid) exactly once.
 template <class F>
@@ -988,6 +1014,13 @@ __device__ __forceinline__ void iterate_tile(
         // correspondences to be of use
         prefetch = predicted && 4 * n_predicted <= nb;
     }
+    // Behind the flag rows: per tile the position of the last point of the tile that had to be
+    // searched once the registration had settled.  Such points are near-ties that come back
+    // launch after launch; the last wave asks for the lines their search reads while the first
+    // wave solves, so that the search, which ends the launch, finds them in the cache.
+    float4 *const hints = reinterpret_cast<float4 *>(ps.active + kFlagRows * kFlagWords);
+    float4 hint = make_float4(__int_as_float(0x7fc00000), 0.f, 0.f, 0.f);
+    if (APPLY && CERTIFY && prefetch && wv == kItThreads / 64 - 1) hint = hints[tile];
     const long long tile0 = (long long)tile * kItTile;
     // everything per point is addressed as (array + tile0)[small index]: a uniform base
     // and a 32-bit offset per thread
@@ -1034,7 +1067,7 @@ __device__ __forceinline__ void iterate_tile(
     // registers are never alive together.) ----
     Float3 tp[NP], nv[NP];
     float lb[NP];
-    float touched = 0.f;
+    float touched = 0.f, touched_too = 0.f;
     double R0 = 1, R1 = 0, R2 = 0, R3 = 0, R4 = 1, R5 = 0, R6 = 0, R7 = 0, R8 = 1, T0 = 0, T1 = 0,
            T2 = 0;
     if (APPLY && !solve_now) {
@@ -1078,12 +1111,13 @@ __device__ __forceinline__ void iterate_tile(
                 // and the two lines of the tile's old sums, which the end of the block asks for
                 touched = (float)partials[(size_t)tile * kNumSums + 16 * (u - NP * 18)];
             }
+            if (wv == kItThreads / 64 - 1) probe_touch(g, hint.x, hint.y, hint.z, touched, touched_too);
         }
         __syncthreads();
         R0 = shRT[0]; R1 = shRT[1]; R2 = shRT[2]; R3 = shRT[3]; R4 = shRT[4]; R5 = shRT[5];
         R6 = shRT[6]; R7 = shRT[7]; R8 = shRT[8]; T0 = shRT[9]; T1 = shRT[10]; T2 = shRT[11];
     }
-    asm volatile("" ::"v"(touched));   // the touching loads are issued whatever the optimiser thinks of them
+    asm volatile("" ::"v"(touched), "v"(touched_too));   // the touching loads are issued whatever the optimiser thinks of them
     SVICP_STAMP(1);
 
     // ---- C: update (CPoint2PlaneICP.cpp:44-49) ----
@@ -1299,6 +1333,8 @@ __device__ __forceinline__ void iterate_tile(
                   (unsigned long long)total);
     if (ps.active && threadIdx.x == 64)
         atomicOr(ps.active + (iter % kFlagRows) * kFlagWords + (tile >> 6), 1ull << (tile & 63));
+    // the first of the few points this tile had to search: where the next launch looks ahead
+    if (APPLY && CERTIFY && fixed_tile < 0 && few && total > 0 && threadIdx.x == 65) hints[tile] = queue[0];
     SVICP_STAMP(7);
 }
 
