@@ -167,17 +167,18 @@ constexpr unsigned kQuadBig = 0xffffffffu;
 __device__ __forceinline__ void probe_runs(const GridDesc &g, size_t e, uint2 (&run)[4])
 {
     const uint4 c = g.quad[e];
-    if (__builtin_expect(c.w == kQuadBig, 0)) {
-        const uint4 a = g.quad_big[2 * (size_t)c.x], b = g.quad_big[2 * (size_t)c.x + 1];
-        run[0] = make_uint2(a.x, a.y); run[1] = make_uint2(a.z, a.w);
-        run[2] = make_uint2(b.x, b.y); run[3] = make_uint2(b.z, b.w);
-        return;
-    }
+    // (all four words are used before the branch: the record stays one 16-byte load, and the
+    // packed form's runs are ready without waiting for the branch)
     const unsigned s1 = c.x + (c.z & 0xffffu), s3 = c.y + (c.z >> 16);
     run[0] = make_uint2(c.x, c.x + (c.w & 0xffu));
     run[1] = make_uint2(s1, s1 + ((c.w >> 8) & 0xffu));
     run[2] = make_uint2(c.y, c.y + ((c.w >> 16) & 0xffu));
     run[3] = make_uint2(s3, s3 + (c.w >> 24));
+    if (__builtin_expect(c.w == kQuadBig, 0)) {
+        const uint4 a = g.quad_big[2 * (size_t)c.x], b = g.quad_big[2 * (size_t)c.x + 1];
+        run[0] = make_uint2(a.x, a.y); run[1] = make_uint2(a.z, a.w);
+        run[2] = make_uint2(b.x, b.y); run[3] = make_uint2(b.z, b.w);
+    }
 }
 
 // Walks four runs of candidates as one flat list, CH at a time.  `fetch(j)` returns point j
