@@ -1569,9 +1569,14 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
             d2_out[o] = hit ? best : INFINITY;
             continue;
         }
+        // The capped probe has seen every target point in the cube [q - rr, q + rr] (its runs
+        // span the quarter cells that hold the cube, not the whole 2 x 2 x 2 cells): a best
+        // distance inside rr is final.  Anything else starts over with the box of ring 0 in
+        // full (the probe's candidates are met again; the best so far carries over).
+        const float r0 = g.rr * (1.0f - 1e-5f) - g.cov_slack;
+        bool done = bpos >= 0 && r0 > 0.f && best <= r0 * r0;
         int cx, cy, cz;
         clamped_origin(g, qx, qy, qz, cx, cy, cz);
-        bool done = false;
         auto visit = [&](unsigned j) {
             float4 p = g.pts[j];
             float d = dist2(qx, qy, qz, p);
@@ -1580,27 +1585,22 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
         };
         // the box of the previous ring (already scanned): empty before the first scan
         int px0 = 0, px1 = -1, py0 = 0, py1 = -1, pz0 = 0, pz1 = -1;
-        for (int ring = 0; ring <= kMaxRing; ++ring) {
+        for (int ring = 0; ring <= kMaxRing && !done; ++ring) {
             int x0, x1, y0, y1, z0, z1;
             float rho = ring_box(g, qx, qy, qz, cx, cy, cz, ring, x0, x1, y0, y1, z0, z1);
-            if (ring > 0 || bpos < 0) {
-                // ring 0 was scanned by nn_capped unless the probe left the grid; later rings
-                // scan only the shell around the box already seen (the best so far carries over)
-                if (px1 < px0) {
-                    scan_box(g, x0, x1, y0, y1, z0, z1, visit);
-                } else {
-                    if (z0 < pz0) scan_box(g, x0, x1, y0, y1, z0, pz0 - 1, visit);
-                    if (z1 > pz1) scan_box(g, x0, x1, y0, y1, pz1 + 1, z1, visit);
-                    if (y0 < py0) scan_box(g, x0, x1, y0, py0 - 1, pz0, pz1, visit);
-                    if (y1 > py1) scan_box(g, x0, x1, py1 + 1, y1, pz0, pz1, visit);
-                    if (x0 < px0) scan_box(g, x0, px0 - 1, py0, py1, pz0, pz1, visit);
-                    if (x1 > px1) scan_box(g, px1 + 1, x1, py0, py1, pz0, pz1, visit);
-                }
-                px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;
+            // later rings scan only the shell around the box already seen
+            if (px1 < px0) {
+                scan_box(g, x0, x1, y0, y1, z0, z1, visit);
             } else {
-                px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;   // what nn_capped saw
+                if (z0 < pz0) scan_box(g, x0, x1, y0, y1, z0, pz0 - 1, visit);
+                if (z1 > pz1) scan_box(g, x0, x1, y0, y1, pz1 + 1, z1, visit);
+                if (y0 < py0) scan_box(g, x0, x1, y0, py0 - 1, pz0, pz1, visit);
+                if (y1 > py1) scan_box(g, x0, x1, py1 + 1, y1, pz0, pz1, visit);
+                if (x0 < px0) scan_box(g, x0, px0 - 1, py0, py1, pz0, pz1, visit);
+                if (x1 > px1) scan_box(g, px1 + 1, x1, py0, py1, pz0, pz1, visit);
             }
-            if (rho == INFINITY || (bpos >= 0 && rho > 0.f && best <= rho * rho)) { done = true; break; }
+            px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;
+            if (rho == INFINITY || (bpos >= 0 && rho > 0.f && best <= rho * rho)) done = true;
         }
         if (done) {
             idx_out[o] = bpos >= 0 ? bidx : -1;

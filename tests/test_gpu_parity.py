@@ -507,6 +507,25 @@ def test_exact_and_capped_search_agree_within_threshold(ctx, po):
     assert ctx.time_nn(exact=True, reps=2) > 0 and ctx.time_nn(exact=False, reps=2) > 0
 
 
+def test_one_neighbour_search_equals_first_of_two(ctx, po):
+    """svicp_knn with k = 1 runs the thread-per-query exact search (what svicp_time_nn times as
+    the exact search), k = 2 the wave-per-query one: two kernels, the same first neighbour, at
+    the start pose (most queries have to look beyond the capped probe's cube, whose runs cover
+    quarter cells, not whole cells) and against the oracle."""
+    from stereovision_amd import synth
+    tgt, nrm, src, _ = synth.make_pair(256)
+    ctx.set_target(tgt, nrm)
+    rng = np.random.default_rng(3)
+    far = (src[:4000] + rng.normal(size=(4000, 3)) * [3, 3, 12]).astype(np.float32)
+    q = np.concatenate([src, far])
+    i1, d1 = ctx.knn(q, 1)
+    i2, d2 = ctx.knn(q, 2)
+    assert np.array_equal(i1[:, 0], i2[:, 0]) and np.array_equal(d1[:, 0], d2[:, 0])
+    oi, od = po.KDTree(tgt).knn(q[::7], 1)
+    assert np.array_equal(i1[::7], oi) and np.array_equal(d1[::7], od)
+    assert (d1[:, 0] > 5.2).mean() > 0.3          # beyond the probe's cube for many
+
+
 def test_probe_records_that_do_not_fit_the_packed_form(ctx, po):
     """Probe records are packed in 16 bytes (run lengths in a byte, the distance between the
     starts of rows next to each other in 16 bits); the records that do not fit are kept in
