@@ -1573,7 +1573,19 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
         // span the quarter cells that hold the cube, not the whole 2 x 2 x 2 cells): a best
         // distance inside rr is final.  Anything else starts over with the box of ring 0 in
         // full (the probe's candidates are met again; the best so far carries over).
-        const float r0 = g.rr * (1.0f - 1e-5f) - g.cov_slack;
+        float r0 = g.rr * (1.0f - 1e-5f) - g.cov_slack;
+        {
+            // what the probe's runs really span: five quarter cells in x from the quarter of
+            // q - rr, two cells in y and in z; the sphere around q inside that box
+            int ax, ay, az, aq;
+            if (probe_origin(g, qx, qy, qz, ax, ay, az, &aq)) {
+                const float hq = g.h * (1.0f / (float)kFineX);
+                float rho = fminf(qx - (g.ox + (float)aq * hq), (g.ox + (float)(aq + kFineRun) * hq) - qx);
+                rho = fminf(rho, fminf(qy - (g.oy + (float)ay * g.h), (g.oy + (float)(ay + 2) * g.h) - qy));
+                rho = fminf(rho, fminf(qz - (g.oz + (float)az * g.h), (g.oz + (float)(az + 2) * g.h) - qz));
+                r0 = fmaxf(r0, rho * (1.0f - 1e-5f) - g.cov_slack);
+            }
+        }
         bool done = bpos >= 0 && r0 > 0.f && best <= r0 * r0;
         int cx, cy, cz;
         clamped_origin(g, qx, qy, qz, cx, cy, cz);
