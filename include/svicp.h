@@ -181,7 +181,9 @@ int svicp_correspondences(svicp_ctx *ctx, int32_t *idx_out, float *d2_out);
  * Exact k nearest target points of each query, k clamped to 128 as
  * setKCount does (CKNNSearch.cpp:60-65).  idx_out: n x k int32 row-major,
  * d2_out: n x k SQUARED distances fp32, ascending; equal distances are ordered
- * by ascending index.  Missing neighbours (k > m): idx -1, d2 +inf. */
+ * by ascending index.  Missing neighbours (k > m): idx -1, d2 +inf.  A query with a NaN
+ * coordinate (the reference leaves it to FLANN, undefined): k = 1 answers "no neighbour"
+ * (-1, +inf); k > 1 answers NaN distances and indices that mean nothing. */
 int svicp_knn(svicp_ctx *ctx, const float *query_aos, int64_t n, int k,
               int32_t *idx_out, float *d2_out);
 

@@ -1748,8 +1748,10 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_brute_kernel(
         }
         if (threadIdx.x == 0) {
             const long long o = perm ? perm[i] : i;
-            idx_out[o] = g.m > 0 ? si[0] : -1;
-            d2_out[o] = g.m > 0 ? sd[0] : INFINITY;
+            // (a query with a NaN coordinate is nearer to nothing: no neighbour)
+            const bool any = g.m > 0 && si[0] != 0x7fffffff;
+            idx_out[o] = any ? si[0] : -1;
+            d2_out[o] = any ? sd[0] : INFINITY;
         }
         __syncthreads();
     }

@@ -524,6 +524,12 @@ def test_one_neighbour_search_equals_first_of_two(ctx, po):
     oi, od = po.KDTree(tgt).knn(q[::7], 1)
     assert np.array_equal(i1[::7], oi) and np.array_equal(d1[::7], od)
     assert (d1[:, 0] > 5.2).mean() > 0.3          # beyond the probe's cube for many
+    # a query with a NaN coordinate: no neighbour with k = 1; with k > 1 the distances are NaN
+    bad = np.float32([[np.nan, 0, 0], [1, 2, np.nan]])
+    bi, bd = ctx.knn(np.concatenate([bad, src[:3]]), 1)
+    assert (bi[:2] == -1).all() and np.isinf(bd[:2]).all() and (bi[2:, 0] >= 0).all()
+    bi, bd = ctx.knn(np.concatenate([bad, src[:3]]), 2)
+    assert np.isnan(bd[:2]).all() and (bi[2:, 0] >= 0).all()
 
 
 def test_probe_records_that_do_not_fit_the_packed_form(ctx, po):
