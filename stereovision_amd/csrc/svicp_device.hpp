@@ -385,6 +385,31 @@ __device__ __forceinline__ void scan_box(const GridDesc &g, int x0, int x1, int 
             }
 }
 
+// The same walk with the points loaded four at a time and handed to `visit(j, point)`: the
+// loads of a group are in flight together, one trip to memory per four candidates instead of
+// one per candidate (a place past the end of the run reads the run's last point again, which
+// changes nothing under a strict order).
+template <class F>
+__device__ __forceinline__ void scan_box_points(const GridDesc &g, int x0, int x1, int y0, int y1,
+                                                int z0, int z1, F &&visit)
+{
+    for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y)
+            for (int bx = x0 >> 2; bx <= (x1 >> 2); ++bx) {
+                int rank = g.dir[((z >> 2) * g.nby + (y >> 2)) * g.nbx + bx];
+                if (rank < 0) continue;
+                int xa = max(x0, bx * 4), xb = min(x1, bx * 4 + 3);
+                int base = rank * 64 + (((z & 3) << 4) | ((y & 3) << 2));
+                unsigned s = g.run2[base + (xa & 3)].x;
+                unsigned e = g.end1[base + (xb & 3)];
+                for (unsigned j = s; j < e; j += 4) {
+                    const unsigned j1 = min(j + 1, e - 1), j2 = min(j + 2, e - 1), j3 = min(j + 3, e - 1);
+                    const float4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
+                    visit(j, p0); visit(j1, p1); visit(j2, p2); visit(j3, p3);
+                }
+            }
+}
+
 // Box of ring `ring` around the probe origin, clipped; returns the radius
 // around q that the box is certain to cover (+inf once it spans the grid).
 __device__ __forceinline__ float ring_box(const GridDesc &g, float qx, float qy, float qz, int cx,
@@ -1589,8 +1614,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
         bool done = bpos >= 0 && r0 > 0.f && best <= r0 * r0;
         int cx, cy, cz;
         clamped_origin(g, qx, qy, qz, cx, cy, cz);
-        auto visit = [&](unsigned j) {
-            float4 p = g.pts[j];
+        auto visit = [&](unsigned j, const float4 &p) {
             float d = dist2(qx, qy, qz, p);
             int id = __float_as_int(p.w);
             if (better(d, id, best, bidx)) { best = d; bpos = (int)j; bidx = id; }
@@ -1602,14 +1626,14 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
             float rho = ring_box(g, qx, qy, qz, cx, cy, cz, ring, x0, x1, y0, y1, z0, z1);
             // later rings scan only the shell around the box already seen
             if (px1 < px0) {
-                scan_box(g, x0, x1, y0, y1, z0, z1, visit);
+                scan_box_points(g, x0, x1, y0, y1, z0, z1, visit);
             } else {
-                if (z0 < pz0) scan_box(g, x0, x1, y0, y1, z0, pz0 - 1, visit);
-                if (z1 > pz1) scan_box(g, x0, x1, y0, y1, pz1 + 1, z1, visit);
-                if (y0 < py0) scan_box(g, x0, x1, y0, py0 - 1, pz0, pz1, visit);
-                if (y1 > py1) scan_box(g, x0, x1, py1 + 1, y1, pz0, pz1, visit);
-                if (x0 < px0) scan_box(g, x0, px0 - 1, py0, py1, pz0, pz1, visit);
-                if (x1 > px1) scan_box(g, px1 + 1, x1, py0, py1, pz0, pz1, visit);
+                if (z0 < pz0) scan_box_points(g, x0, x1, y0, y1, z0, pz0 - 1, visit);
+                if (z1 > pz1) scan_box_points(g, x0, x1, y0, y1, pz1 + 1, z1, visit);
+                if (y0 < py0) scan_box_points(g, x0, x1, y0, py0 - 1, pz0, pz1, visit);
+                if (y1 > py1) scan_box_points(g, x0, x1, py1 + 1, y1, pz0, pz1, visit);
+                if (x0 < px0) scan_box_points(g, x0, px0 - 1, py0, py1, pz0, pz1, visit);
+                if (x1 > px1) scan_box_points(g, px1 + 1, x1, py0, py1, pz0, pz1, visit);
             }
             px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;
             if (rho == INFINITY || (bpos >= 0 && rho > 0.f && best <= rho * rho)) done = true;
