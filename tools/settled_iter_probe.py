@@ -1,5 +1,8 @@
+"""Development probe: kernel time of each settled launch of the benchmark step (events around eager
+launches minus an empty event pair) beside the number of points it searched; the launches with and
+without a search apart.  The library is the one named by SVICP_LIBRARY."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import stereovision_amd as sv
 from stereovision_amd import synth
