@@ -458,11 +458,14 @@ int ensure_iteration_buffers(svicp_ctx *ctx, int iters)
     ctx->nb = nb; ctx->chunk = chunk;
     HIPCHK(ctx->partials.reserve(sizeof(double) * kNumSums * nb));
     if (!ctx->tile_flags.p) {
-        HIPCHK(ctx->tile_flags.reserve(kFlagBytes));
-        HIPCHK(hipMemsetAsync(ctx->tile_flags.p, 0, sizeof(unsigned long long) * kFlagRows * kFlagWords, ctx->stream));
+        // (a pair of an arena batch runs in the batch kernel, which gives every block its tile
+        // and looks ahead for nothing: the rows alone)
+        const size_t rows = sizeof(unsigned long long) * kFlagRows * kFlagWords;
+        HIPCHK(ctx->tile_flags.reserve(ctx->lean() ? rows : kFlagBytes));
+        HIPCHK(hipMemsetAsync(ctx->tile_flags.p, 0, rows, ctx->stream));
         // (the look-ahead positions behind the rows start as NaN: nothing to look ahead for)
-        HIPCHK(hipMemsetAsync(ctx->tile_flags.as<char>() + sizeof(unsigned long long) * kFlagRows * kFlagWords, 0xff,
-                              sizeof(float4) * kFlagCap, ctx->stream));
+        if (!ctx->lean())
+            HIPCHK(hipMemsetAsync(ctx->tile_flags.as<char>() + rows, 0xff, sizeof(float4) * kFlagCap, ctx->stream));
     }
     HIPCHK(ctx->state.reserve(sizeof(IcpState)));
     if (iters > ctx->hist_cap) {
@@ -504,7 +507,9 @@ LoopBufs own_bufs(svicp_ctx *ctx)
     b.xhist = ctx->xhist.as<double>();
     b.ihist = ctx->ihist.as<double>();
     b.state = ctx->state.as<IcpState>();
-    b.flags = ctx->nb <= kFlagCap ? ctx->tile_flags.as<unsigned long long>() : nullptr;
+    // (a pair lent by an arena batch keeps the rows only, without the look-ahead positions
+    // behind them: it runs with the fixed block order)
+    b.flags = ctx->nb <= kFlagCap && !ctx->lean() ? ctx->tile_flags.as<unsigned long long>() : nullptr;
     return b;
 }
 
