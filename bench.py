@@ -58,7 +58,7 @@ def parse():
 def profile_figure(name):
     """A figure kept under profiles/ by the counter passes of this same command (rocprofv3
     --pmc cannot run inside the timed process); None when the file or the key is missing."""
-    for f in ("r02_traffic.json", "r01_traffic.json"):
+    for f in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         path = os.path.join(ROOT, "profiles", f)
         if os.path.exists(path):
             with open(path) as fh:
@@ -71,17 +71,30 @@ def profile_figure(name):
 def profile_counters(kernel_contains, regime_contains=""):
     """The derived counter figures (busy fractions, hit rates, wait shares) the counter passes
     left under profiles/ for one kernel and regime; {} when there are none."""
-    path = os.path.join(ROOT, "profiles", "r02_counters.json")
-    if not os.path.exists(path):
-        return {}
-    with open(path) as fh:
-        kernels = json.load(fh).get("kernels", {})
-    for name, entry in kernels.items():
-        if kernel_contains in name and regime_contains in name:
-            out = {k: v for k, v in entry.items() if k != "counters" and not isinstance(v, dict)}
-            out["source"] = "profiles/r02_counters.json"
-            return out
+    for f in ("r03_counters.json", "r02_counters.json"):
+        path = os.path.join(ROOT, "profiles", f)
+        if not os.path.exists(path):
+            continue
+        with open(path) as fh:
+            kernels = json.load(fh).get("kernels", {})
+        for name, entry in kernels.items():
+            if kernel_contains in name and regime_contains in name:
+                out = {k: v for k, v in entry.items() if k != "counters" and not isinstance(v, dict)}
+                out["source"] = "profiles/" + f
+                return out
     return {}
+
+
+# Exit status of the process, decided from what the legs left behind: the line is written in
+# every case, but a run that gave up on a leg must not look like a clean one to whoever
+# records only the status.
+EXIT_OK, EXIT_FAILED_LEG, EXIT_UNFINISHED_LEG = 0, 2, 3
+
+
+def exit_status(failed_legs, unfinished_leg):
+    if unfinished_leg:
+        return EXIT_UNFINISHED_LEG
+    return EXIT_FAILED_LEG if failed_legs else EXIT_OK
 
 
 def main():
@@ -132,6 +145,13 @@ def main():
         t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def sum_over_ranks(values):
+        if not distributed:
+            return [float(v) for v in values]
+        t = torch.tensor(list(values), dtype=torch.float64, device=f"cuda:{local}" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
 
     n = args.side * args.side
     tgt, nrm, src, pose = synth.make_pair(args.side, pair=rank)
@@ -208,6 +228,10 @@ def main():
     loads_ms, loads_instr = ctx.time_gather(True, 0, 20)
     hashed_ms, hashed_instr = ctx.time_gather(False, 16, 5)
     bytes_nn = 20.0 * n + 16.0 * len(tgt)
+    # queries/s over all ranks: every rank searches its own million queries in its own replica
+    # of a target (queries sharded, target replicated)
+    nn_rates = sum_over_ranks([n / (nn_capped_ms * 1e-3), n / (nn_exact_ms * 1e-3),
+                               n / (nn_capped_start_ms * 1e-3), n / (nn_exact_start_ms * 1e-3)])
     # without the shortcut for points whose correspondence provably did not change
     ctx.set_options(coherent=0)
     ctx.run(args.iters)
@@ -262,7 +286,10 @@ def main():
             "config": {
                 "workload": f"configs[1]: synthetic {args.side}^2-point source/target pair with "
                             f"normals, point-to-plane ICP, {args.iters} iters per step, "
-                            "one independent pair per GPU",
+                            "one independent pair per GPU; start pose Rz(0.6 deg) Ry(-0.4 deg) "
+                            "Rx(0.5 deg), t = (-0.4, 1.2, 0.8), which leaves 16 % of the source within "
+                            "the weight threshold at iteration 0 (value_inlier_pose: the same pair "
+                            "from the pose that leaves 70 %)",
                 "points": n, "iters_per_step": args.iters,
             },
             # the dominant kernel in the regime the byte model describes: a launch that searches
@@ -301,12 +328,6 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ((traffic_settled / (settled_ms * 1e-3) / 1e9) / HBM_PEAK_GBS) if traffic_settled else None,
                 "launches_of_this_regime_per_step": int(settled.sum()),
-                "where_the_time_goes_us": {"between launches": 1.4, "until a launch's first loads are back": 1.3,
-                                           "redundant solve": 1.5, "update and all-points-still test": 0.7,
-                                           "tiles that still have work (re-prove, re-accumulate, block sums)": 3.2,
-                                           "search of a near-tie point (17 of 25 settled launches of a step)": 1.8,
-                                           "source": "per-block wall-clock stamps of a build with -DSVICP_TRACE "
-                                                     "(tools/trace_probe.py); the stamps add about 0.1 us each"},
             },
             # the standalone correspondence kernel (the reduction has no kernel of its own: it is
             # fused into icp_iterate_kernel)
@@ -337,13 +358,16 @@ def main():
             "value_searching_every_point_every_iteration": full_search_value,
             "value_inlier_pose": value_inlier_pose,
             "value_sharded": value_sharded,
-            "nn_queries_per_s": {"capped": n / (nn_capped_ms * 1e-3),
-                                 "exact": n / (nn_exact_ms * 1e-3),
+            "nn_queries_per_s": {"capped": nn_rates[0],
+                                 "exact": nn_rates[1],
                                  "capped_GBs": bytes_nn / (nn_capped_ms * 1e-3) / 1e9,
                                  "positions": "after registration (every source point has a close "
                                               "target point)",
-                                 "capped_at_start": n / (nn_capped_start_ms * 1e-3),
-                                 "exact_at_start": n / (nn_exact_start_ms * 1e-3)},
+                                 "capped_at_start": nn_rates[2],
+                                 "exact_at_start": nn_rates[3],
+                                 "summed_over_ranks": world,
+                                 "note": "whole-job rates: each rank's own queries against its own "
+                                         "replica of a target; capped_GBs is rank 0's"},
             "grid_build_ms": grid_build_s * 1e3,
             "grid_build_ms_buffers_in_place": grid_rebuild_s * 1e3,
             "final_step_norm": info.step_norm,
@@ -378,8 +402,11 @@ def main():
 
     def watchdog():
         if not finished.wait(args.leg_budget_s):
-            write_line(f"{current[0]}: no return within {args.leg_budget_s} s of the headline measurement")
-            os._exit(0)
+            unfinished = f"{current[0]}: no return within {args.leg_budget_s} s of the headline measurement"
+            # every rank names the leg it is stuck in; rank 0 writes the line with what has finished
+            os.write(2, f"bench.py rank {rank}: giving up on {unfinished}\n".encode())
+            write_line(unfinished)
+            os._exit(exit_status(failed, unfinished))
     threading.Thread(target=watchdog, daemon=True).start()
 
     def guard(name, leg):
@@ -388,6 +415,7 @@ def main():
             return leg()
         except Exception as e:                      # noqa: BLE001 - reported in the line
             failed[name] = f"{type(e).__name__}: {e}"[:400]
+            os.write(2, f"bench.py rank {rank}: leg {name} failed: {failed[name]}\n".encode())
             return None
 
     # ---- sharded leg: one large pair, source split over the ranks, the loop inside the
@@ -700,6 +728,10 @@ def main():
     ctx.close()
     if distributed:
         dist.destroy_process_group()
+    # the line is out; a leg that failed still makes the run a failed one
+    status = exit_status(failed, None)
+    if status != EXIT_OK:
+        sys.exit(status)
 
 
 if __name__ == "__main__":

@@ -42,13 +42,20 @@ public:
                          : SVICP_ERR_NO_DEVICE;
     }
     // :19-22, a view.  run() copies the buffer to the device and back on every call, so a
-    // large one is pinned in place here (an addition; it stays the caller's memory)
+    // large one is pinned in place here (an addition; it stays the caller's memory).
+    // LIFETIME, stricter than the reference's view: a pinned buffer must stay allocated until
+    // this object is destroyed or setMoveData is given another buffer (the registration is
+    // undone there, and undoing it on freed memory is undefined).  A caller that frees or
+    // reallocates its cloud earlier calls setPinMoveData(false) before setMoveData: the copies
+    // then take the pageable path and the object keeps nothing but the view.
+    void setPinMoveData(bool pin) { m_pin = pin; }
     void setMoveData(flann::Matrix<float> move)
     {
         if (m_pinned) { svicp_host_unregister(m_pinned); m_pinned = nullptr; }
         m_moveData = move;
         const int64_t bytes = (int64_t)move.rows * 3 * (int64_t)sizeof(float);
-        if (m_ctx && move.ptr() && bytes >= (1 << 20) && svicp_host_register(move.ptr(), bytes) == SVICP_OK)
+        if (m_pin && m_ctx && move.ptr() && bytes >= (1 << 20) &&
+            svicp_host_register(move.ptr(), bytes) == SVICP_OK)
             m_pinned = move.ptr();
     }
     void setEpsilon(float eps) { m_eps = eps; }                          // :23-26, never read
@@ -106,6 +113,7 @@ private:
     int m_count;
     svicp_ctx *m_ctx;
     float *m_pinned = nullptr;
+    bool m_pin = true;
     int m_status;
     svicp_info m_info;
     double m_T[16];

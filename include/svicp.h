@@ -143,10 +143,15 @@ int svicp_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info *info
  * hipMalloc).  It has no counterpart in the reference.  The same kernels as
  * svicp_run, launched one by one on the context's stream; nothing is allocated,
  * freed, instantiated or synchronised: the sums, the iteration state and the
- * history live in a file-scope device array of about 1.2 MB that every context on
- * that device shares and that keeps the last call's contents (what must start at
- * zero is cleared by the call).  Two such calls that overlap on one GPU (different
- * streams, or contexts used by different threads) race; calls on one stream do not.
+ * history live in a file-scope device array (about 9.7 MB per GPU) cut into 8
+ * workspaces of 1.2 MB.  A context takes a free workspace at its first call and
+ * keeps it until svicp_destroy, so contexts that enqueue on their own streams at
+ * the same time do not touch each other's sums; a ninth context on one device is
+ * refused (SVICP_ERR_ARG) while eight others hold theirs.  A workspace keeps the
+ * last call's contents (what must start at zero is cleared by the call).  What
+ * still races: the SAME context's calls (or a recorded graph of them) running at
+ * the same time on different streams; a recording replayed after its context was
+ * destroyed and the workspace handed to another.
  * Limits, rejected with SVICP_ERR_ARG: iterations <= 128, source <= 4194304 points.
  * The clouds are the resident ones (svicp_set_target / svicp_set_source allocate;
  * call them beforehand).  dev_out20: DEVICE memory, 20 doubles, written by the last
@@ -238,9 +243,13 @@ int svicp_shard_run_mode(const svicp_ctx *ctx, int *captured, int *world_size);
  * which tiles or ranks are added up), scaled by bounds that include the number of source
  * points.  Ranks that exchange sums must scale alike: each rank tells its context the size
  * of the WHOLE source, the same number on every rank, after svicp_set_source and before
- * svicp_shard_begin.  svicp_shard_run needs no such call (it agrees on the number over its
- * communicator).  Without it a context scales for its own part only, which is right for one
- * rank. */
+ * svicp_shard_begin.  svicp_shard_run needs no such call: with more than one rank EVERY call
+ * of it starts with one small blocking all-reduce over its communicator (each rank's point
+ * count and the total it was told, if any), whatever the ranks did before, so ranks that
+ * changed their part of the source and ranks that did not still make the same collective
+ * calls; the total is the largest one any rank was told, else the largest part times the
+ * number of ranks.  Without either a context scales for its own part only, which is right
+ * for one rank. */
 int svicp_shard_set_total(svicp_ctx *ctx, int64_t total_points);
 
 /* Resets the accumulated transform and the iteration counter. */

@@ -127,7 +127,12 @@ constexpr size_t kEnqOffFlags = kEnqOffIhist + enq_align(sizeof(double) * 4 * kE
 constexpr size_t kFlagBytes = sizeof(unsigned long long) * kFlagRows * kFlagWords + sizeof(float4) * kFlagCap;   // flag rows, then a look-ahead position per tile
 constexpr size_t kEnqOffPartials = kEnqOffFlags + enq_align(kFlagBytes);
 constexpr size_t kEnqBytes = kEnqOffPartials + enq_align(sizeof(double) * kNumSums * kEnqMaxTiles);
-static __device__ __align__(256) unsigned char scratch[kEnqBytes];   // about 1.2 MB
+// The array is cut into kEnqSlots workspaces of kEnqBytes (about 1.2 MB each).  A context takes
+// one the first time it calls svicp_run_enqueue and keeps it until it is destroyed, so contexts
+// that enqueue on streams of their own at the same time never share a workspace; one context
+// has one stream, and calls on one stream are ordered.
+constexpr int kEnqSlots = 8;
+static __device__ __align__(256) unsigned char scratch[kEnqSlots * kEnqBytes];   // about 9.7 MB
 
 namespace {
 // Device address of `scratch` on each device (the array's name is a host-side stand-in, not
@@ -135,6 +140,24 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 unsigned char *g_scratch_ptr[kMaxDevices] = {};
+unsigned g_scratch_taken[kMaxDevices] = {};     // bit s: workspace s of that device is some context's
+
+// A free workspace of `device` (its number, or -1 when every one is taken), and its return.
+int take_scratch_slot(int device)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (device < 0 || device >= kMaxDevices) return -1;
+    for (int s = 0; s < kEnqSlots; ++s)
+        if (!(g_scratch_taken[device] & (1u << s))) { g_scratch_taken[device] |= 1u << s; return s; }
+    return -1;
+}
+
+void return_scratch_slot(int device, int slot)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (device >= 0 && device < kMaxDevices && slot >= 0 && slot < kEnqSlots)
+        g_scratch_taken[device] &= ~(1u << slot);
+}
 
 hipError_t scratch_on_current_device(int device, unsigned char **out)
 {
@@ -185,6 +208,7 @@ struct svicp_ctx {
     int fx_host[kNumSums] = {};
     float tgt_maxabs = 0.f, nrm_maxabs = 1.f;
     int64_t total_points = 0;      // source points over ALL ranks of a sharded run (0: this context's own)
+    int64_t explicit_total = 0;    // what svicp_shard_set_total gave for the present source (0: nothing)
     IcpState *h_state = nullptr;   // pinned and mapped: the kernel that ends a run writes it
     IcpState *h_state_dev = nullptr;
     bool h_state_pinned = false;   // h_state came from hipHostMalloc (a batch member's is plain memory)
@@ -207,6 +231,7 @@ struct svicp_ctx {
     int g_iters_shard = -1;
     bool shard_capture_failed = false;   // this runtime would not capture the collective: eager from then on
     unsigned char *enq_scratch = nullptr;   // this device's copy of `scratch`
+    int enq_slot = -1;                      // the workspace inside it this context has taken (svicp_run_enqueue)
 
     // point-to-point variant
     DevBuf p2p_sums, rthist;
@@ -737,6 +762,7 @@ int svicp_destroy(svicp_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     drop_graph(ctx);
     if (ctx->comm) { (void)rccl_api()->CommDestroy(ctx->comm); ctx->comm = nullptr; }
+    return_scratch_slot(ctx->device, ctx->enq_slot);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     DevBuf *bufs[] = { &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->quad, &ctx->quad_big, &ctx->g_dev, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx,
                        &ctx->wy, &ctx->wz, &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->tile_flags, &ctx->perm,
@@ -1107,6 +1133,7 @@ int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_source = true;
     ctx->total_points = 0;          // a sharded run agrees on the total again
+    ctx->explicit_total = 0;
     return update_fixed_point(ctx);
 }
 
@@ -1255,10 +1282,18 @@ int svicp_run_enqueue(svicp_ctx *ctx, int iterations, double *dev_out20)
     if (nb > kEnqMaxTiles)
         return fail(ctx, SVICP_ERR_ARG,
                     "svicp_run_enqueue: the source exceeds the workspace (4194304 points at most)");
+    if (ctx->enq_slot < 0) {
+        ctx->enq_slot = take_scratch_slot(ctx->device);
+        if (ctx->enq_slot < 0)
+            return fail(ctx, SVICP_ERR_ARG,
+                        "svicp_run_enqueue: all 8 workspaces of this device belong to other contexts "
+                        "(a context keeps the one it took until svicp_destroy)");
+    }
     HIPCHK(hipSetDevice(ctx->device));
     if (nb != ctx->nb) drop_graph(ctx);     // (svicp_run's graph bakes the tile count in)
     ctx->nb = nb; ctx->chunk = kItTile;
-    unsigned char *w = ctx->enq_scratch;    // the device address, never the array's name
+    // the device address, never the array's name; this context's own workspace inside it
+    unsigned char *w = ctx->enq_scratch + (size_t)ctx->enq_slot * kEnqBytes;
     LoopBufs b;
     b.state = reinterpret_cast<IcpState *>(w + kEnqOffState);
     b.totals = reinterpret_cast<fx_t *>(w + kEnqOffTotals);
@@ -1446,22 +1481,32 @@ int svicp_shard_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info
     HIPCHK(hipSetDevice(ctx->device));
     int rc = ensure_iteration_buffers(ctx, iterations);
     if (rc) return rc;
-    if (ctx->comm && ctx->comm_world > 1 && ctx->total_points == 0) {
-        // every rank must scale its sums alike: agree on the largest part of the source
-        // (once per source: a blocking exchange of one 64-bit integer)
-        long long *slot = reinterpret_cast<long long *>(ctx->fx_exp.as<int>() + 30);
-        long long mine = (long long)ctx->n, most = 0;
-        HIPCHK(hipMemcpyAsync(slot, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
-        ncclResult_t r = rccl_api()->AllReduce(slot, slot, 1, ncclInt64, ncclMax, ctx->comm, ctx->stream);
+    if (ctx->comm && ctx->comm_world > 1) {
+        // Every rank must scale its sums alike.  Whether the ranks exchange anything here must
+        // not depend on one rank's own history (a rank that set a new part of the source, or
+        // called svicp_shard_set_total, while another did not): EVERY call makes the same one
+        // blocking exchange of two 64-bit integers, {this rank's points, the total it was
+        // told or 0}, maximum over the ranks.  The total is the largest one any rank was told,
+        // else the largest part times the number of ranks; the table is uploaded again only
+        // when that changes.
+        long long *slot = reinterpret_cast<long long *>(ctx->rt_apart.as<double>() + 12);
+        long long mine[2] = { (long long)ctx->n, (long long)ctx->explicit_total }, most[2] = { 0, 0 };
+        HIPCHK(hipMemcpyAsync(slot, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+        ncclResult_t r = rccl_api()->AllReduce(slot, slot, 2, ncclInt64, ncclMax, ctx->comm, ctx->stream);
         if (r != ncclSuccess) return fail_rccl(ctx, "ncclAllReduce(max points)", r);
-        HIPCHK(hipMemcpyAsync(&most, slot, sizeof most, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(most, slot, sizeof most, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        ctx->total_points = (int64_t)most * ctx->comm_world;
-        rc = update_fixed_point(ctx);
-        if (rc) return rc;
+        const int64_t agreed = most[1] > 0 ? std::max<int64_t>(most[1], most[0])
+                                           : (int64_t)most[0] * ctx->comm_world;
+        if (agreed != ctx->total_points) {
+            ctx->total_points = agreed;
+            rc = update_fixed_point(ctx);
+            if (rc) return rc;
+        }
     }
     const bool capture = ctx->opt.use_graph && ctx->stream != nullptr && !ctx->shard_capture_failed;
     bool launched = false;
+    std::string capture_error;
     if (capture) {
         if (!ctx->gexec_shard || ctx->g_iters_shard != iterations) {
             if (ctx->gexec_shard) { (void)hipGraphExecDestroy(ctx->gexec_shard); ctx->gexec_shard = nullptr; }
@@ -1475,6 +1520,10 @@ int svicp_shard_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info
             if (graph) (void)hipGraphDestroy(graph);
             if (rc != SVICP_OK || e != hipSuccess || !ctx->gexec_shard) {
                 // a runtime that cannot capture the collective: launch one by one from now on
+                // (what the capture failed with is kept: if the launches one by one fail too,
+                // both messages are reported)
+                capture_error = rc != SVICP_OK ? ctx->err
+                                               : std::string("capture: ") + hipGetErrorString(e);
                 (void)hipGetLastError();
                 ctx->gexec_shard = nullptr;
                 ctx->shard_capture_failed = true;
@@ -1489,7 +1538,10 @@ int svicp_shard_run(svicp_ctx *ctx, int iterations, double T_out[16], svicp_info
     }
     if (!launched) {
         rc = enqueue_shard_loop(ctx, iterations);
-        if (rc) return rc;
+        if (rc) {
+            if (!capture_error.empty()) ctx->err += " (after the graph capture had failed with: " + capture_error + ")";
+            return rc;
+        }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));   // the last kernel wrote h_state
     ctx->cur = iterations > 1 ? 1 : 0;
@@ -1516,7 +1568,8 @@ int svicp_shard_set_total(svicp_ctx *ctx, int64_t total_points)
     if (!ctx->have_target || !ctx->have_source)
         return fail(ctx, SVICP_ERR_ARG, "svicp_shard_set_total: set the target and the source first");
     HIPCHK(hipSetDevice(ctx->device));
-    ctx->total_points = std::max<int64_t>(total_points, ctx->n);
+    ctx->explicit_total = std::max<int64_t>(total_points, ctx->n);
+    ctx->total_points = ctx->explicit_total;
     return update_fixed_point(ctx);
 }
 

@@ -500,7 +500,13 @@ class CPoint2PlaneICP:
             self._pinned = None
 
     def __del__(self):
-        self._unpin()
+        # (at interpreter shutdown the library loader itself may be gone: nothing to undo then.
+        # The array stays alive as long as this object refers to it, so the registration never
+        # outlives the memory.)
+        try:
+            self._unpin()
+        except Exception:       # noqa: BLE001
+            pass
 
     def setEpsilon(self, eps):
         self.m_eps = float(eps)            # stored and never read, as in the reference

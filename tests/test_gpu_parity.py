@@ -679,6 +679,35 @@ def test_full_size_iterations_against_oracle(ctx, po, side, iters, frac):
     assert np.abs(ctx.get_source() - r["src"]).max() <= 2e-4        # a few ulp at |x| ~ 1e4
 
 
+@pytest.mark.parametrize("frac", [None, 0.7])
+def test_one_million_points_thirty_iterations_against_oracle(ctx, po, frac):
+    """The headline configuration from end to end (CPoint2PlaneICP.cpp:40-57: 30 solves, 29 updates
+    of the source), both start poses, against the oracle on all host threads.  Iterations 5 to 29
+    are the settled regime -- tiles skipped, correspondences proven instead of searched, blocks
+    reordered, near-tie points looked ahead for -- so every shortcut is held against a run that
+    takes none.  Inliers equal in every iteration, every solve within 1e-9 (angles) and
+    1e-9 x extent (translation), the accumulated transform within the 1e-6 / 1e-6 x extent this
+    path is held to (measured: far inside), the moved source within an fp32 ulp."""
+    from stereovision_amd import synth
+    tgt, nrm, src, _ = synth.make_pair(1024, inlier_frac=frac)
+    ctx.set_target(tgt, nrm)
+    ctx.set_source(src)
+    T, info = ctx.run(30)
+    X, I = ctx.history()
+    searched = ctx.search_counts()
+    r = po.icp_point2plane(po.KDTree(tgt), nrm, src, 30, threads=po.max_threads(), history=False)
+    extent = float(np.ptp(tgt, axis=0).max())
+    assert np.array_equal(I[:, 0], r["info"][:, 0])
+    assert np.abs(X[:, :3] - r["X"][:, :3]).max() < 1e-9
+    assert np.abs(X[:, 3:] - r["X"][:, 3:]).max() < 1e-9 * extent
+    Rg, Ro = T[:3, :3], r["trans"][:3, :3]
+    assert np.abs(Rg - Ro).max() < 1e-6 and np.abs(T[:3, 3] - r["trans"][:3, 3]).max() < 1e-6 * extent
+    assert np.abs(T - r["trans"]).max() < 1e-9 * extent            # (what is measured: 1e-12 .. 1e-10)
+    # the settled regime was really exercised
+    assert searched[0] == len(src) and searched[8:].max() < 0.001 * len(src)
+    assert np.abs(ctx.get_source() - r["src"]).max() <= 2.5e-4      # one ulp at |x| ~ 2600
+
+
 def test_search_counts_fall_as_the_registration_settles(ctx):
     from stereovision_amd import synth
     tgt, nrm, src, _ = synth.make_pair(256)
