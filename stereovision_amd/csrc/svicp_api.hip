@@ -83,13 +83,13 @@ struct DevBuf {
 struct Scratch {
     DevBuf tgt_aos, nrm_aos, run2, end1, qrun, big_count;
     DevBuf tmp_aos, keys_a, keys_b, vals_a, vals_b, marks, ranks, block_of_rank, sort_tmp, bbox6;
-    DevBuf knn_idx, knn_d2, unresolved, n_unres, q_soa;
+    DevBuf knn_idx, knn_d2, unresolved, n_unres, q_soa, far_list;
     float *h_small = nullptr;      // pinned: small results on their way back (bounding box, counts)
     void release()
     {
         DevBuf *bufs[] = { &tgt_aos, &nrm_aos, &run2, &end1, &qrun, &big_count, &tmp_aos, &keys_a, &keys_b, &vals_a, &vals_b,
                            &marks, &ranks, &block_of_rank, &sort_tmp, &bbox6, &knn_idx, &knn_d2,
-                           &unresolved, &n_unres, &q_soa };
+                           &unresolved, &n_unres, &q_soa, &far_list };
         for (DevBuf *b : bufs) b->release();
         if (h_small) (void)hipHostFree(h_small);
         h_small = nullptr;
@@ -437,25 +437,48 @@ int run_nn1_on(svicp_ctx *ctx, const float *x, const float *y, const float *z, c
 {
     if (n == 0) return SVICP_OK;
     HIPCHK(ctx->scr->unresolved.reserve(sizeof(int) * n));
-    HIPCHK(ctx->scr->n_unres.reserve(sizeof(int)));
+    HIPCHK(ctx->scr->n_unres.reserve(sizeof(int) * 2));
     const int grid = std::min(cdiv(n, kBlockThreads), ctx->num_cus * 8);
     if (!exact) {
         hipLaunchKernelGGL((nn1_kernel<false, 4>), dim3(grid), dim3(kBlockThreads), 0, ctx->stream,
                            ctx->g, x, y, z, perm, (int)n, ctx->opt.dist_threshold, idx, d2, (int *)nullptr,
-                           (int *)nullptr);
+                           (int *)nullptr, (int4 *)nullptr, (int *)nullptr);
         LAUNCHCHK("nn1_kernel");
     } else {
-        HIPCHK(hipMemsetAsync(ctx->scr->n_unres.p, 0, sizeof(int), ctx->stream));
+        // counters: [0] queries left for the exhaustive pass, [1], [2] entries of the lists of parts
+        // of waves that nn1_far_kernel hands on (4 lanes, then single lanes)
+        HIPCHK(ctx->scr->n_unres.reserve(sizeof(int) * 4));
+        HIPCHK(hipMemsetAsync(ctx->scr->n_unres.p, 0, sizeof(int) * 4, ctx->stream));
+        const int waves = cdiv(n, 64);
+        const int cap = (waves + 15) & ~15;
+        HIPCHK(ctx->scr->far_list.reserve(sizeof(int4) * (size_t)cap * 3));
+        int *const n_unres = ctx->scr->n_unres.as<int>();
+        int4 *const list0 = ctx->scr->far_list.as<int4>(), *const list1 = list0 + cap, *const list2 = list1 + cap;
         // one chunk of 256 queries per block: the far queries, which take long, come in
         // stretches, and the dispatcher spreads them best when the blocks are small
         const int grid_exact = (int)std::min<int64_t>(cdiv(n, kBlockThreads), 1 << 20);
         hipLaunchKernelGGL((nn1_kernel<true, 4>), dim3(grid_exact), dim3(kBlockThreads), 0, ctx->stream,
                            ctx->g, x, y, z, perm, (int)n, ctx->opt.dist_threshold, idx, d2,
-                           ctx->scr->unresolved.as<int>(), ctx->scr->n_unres.as<int>());
+                           ctx->scr->unresolved.as<int>(), n_unres, list0, (int *)nullptr);
         LAUNCHCHK("nn1_kernel(exact)");
+        // the waves with queries beyond the probe radius: one candidate box per wave, in LDS (a grid
+        // that fills the GPU; every wave takes listed waves in turn).  A wave whose queries lie
+        // too far apart for one box hands them on to the next launch in 16 parts of 4 lanes, and
+        // such a part as single lanes (a box around one query always works).
+        const int grid_far = (int)std::min<int64_t>(cdiv(waves, kFarThreads / 64), (int64_t)ctx->num_cus * 32);
+        const dim3 fb(kFarThreads);
+        int *const unres = ctx->scr->unresolved.as<int>();
+        hipLaunchKernelGGL(nn1_far_kernel, dim3(grid_far), fb, 0, ctx->stream, ctx->g, x, y, z, perm, (int)n, list0,
+                           (const int *)nullptr, waves, list1, n_unres + 1, cap, 16, 4, idx, d2, unres, n_unres);
+        hipLaunchKernelGGL(nn1_far_kernel, dim3(std::min(grid_far, 2048)), fb, 0, ctx->stream, ctx->g, x, y, z, perm,
+                           (int)n, list1, n_unres + 1, cap, list2, n_unres + 2, cap, 4, 1, idx, d2, unres, n_unres);
+        hipLaunchKernelGGL(nn1_far_kernel, dim3(std::min(grid_far, 2048)), fb, 0, ctx->stream, ctx->g, x, y, z, perm,
+                           (int)n, list2, n_unres + 2, cap, (int4 *)nullptr, (int *)nullptr, 0, 1, 1, idx, d2, unres,
+                           n_unres);
+        LAUNCHCHK("nn1_far_kernel");
         hipLaunchKernelGGL(nn1_brute_kernel, dim3(std::min<int64_t>(n, 2048)), dim3(kBlockThreads),
                            0, ctx->stream, ctx->g, x, y, z, perm, ctx->scr->unresolved.as<int>(),
-                           ctx->scr->n_unres.as<int>(), idx, d2);
+                           n_unres, idx, d2);
         LAUNCHCHK("nn1_brute_kernel");
     }
     return SVICP_OK;
@@ -1642,6 +1665,18 @@ int svicp_shard_finish(svicp_ctx *ctx, double T_out[16], svicp_info *info)
         return fail(ctx, SVICP_ERR_SINGULAR, "svicp_shard_finish: normal matrix not positive definite");
     return SVICP_OK;
 }
+
+#ifdef SVICP_FAR_STATS
+int svicp_debug_far_stats(unsigned long long *out8, int clear)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(svicp::g_far_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (clear) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(svicp::g_far_stats), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 #ifdef SVICP_TRACE
 // development builds only: the phase stamps of the last run (see SVICP_STAMP)

@@ -44,6 +44,31 @@ __device__ unsigned long long g_trace[kTraceIters * kTraceTiles * kTraceStamps];
 #define SVICP_SOLVE_STAMP(k) do { } while (0)
 #endif
 
+// Development builds for the byte budget (-DSVICP_DROP=<bits>): each bit takes ONE stream of
+// memory traffic out of the search and the iteration kernel, so that counter passes over such
+// builds tell how many bytes each array moves (tools/byte_budget.sh).  Results of such a
+// build mean nothing; the product is built without the macro and none of this is compiled in.
+#ifndef SVICP_DROP
+#define SVICP_DROP 0
+#endif
+constexpr unsigned kDrop = SVICP_DROP;
+constexpr int kDropIter = 2;    // the iteration kernel drops its streams in this launch of a run only
+constexpr unsigned kDropSrcWrite = 1,    // the updated coordinates are not stored
+                   kDropStateWrite = 2,  // the per-point state (28 B) is not stored
+                   kDropNrm = 4,         // the winner's normal is not gathered
+                   kDropPts = 8,         // candidates are made up instead of gathered
+                   kDropQuad = 16,       // the probe record is not loaded (no candidates either)
+                   kDropDir = 32,        // nor the directory word
+                   kDropOut = 64;        // nn1_kernel: index and distance are not stored
+
+// A/B builds (-DSVICP_LATE_STATE=k): the per-point state is first written in launch k of a
+// run and first read in launch k + 1 (what a policy that skips the state while the cloud still
+// moves far would do on the benchmark pair with k = 2).
+#ifndef SVICP_LATE_STATE
+#define SVICP_LATE_STATE 0
+#endif
+constexpr int kLateState = SVICP_LATE_STATE;
+
 constexpr int kBlockThreads = 256;
 constexpr int kNumSums = 32;   // 21 JtJ + 6 Jtr + inliers + sum w b^2 + sum w + 2 pad
 // Same-address fp64 atomics serialise in L2 (about 6 ns each): the per-iteration change of
@@ -131,8 +156,13 @@ __device__ __forceinline__ int dir_index(const GridDesc &g, int cx, int cy, int 
 // four runs (8.0 instead of 12.7 per query on the benchmark pair, 3.0 instead of 4.2 chunks
 // of four per wave).  cxq: the quarter's number along x (4 cx + 0..3); scaling by four is
 // exact, so cxq >> 2 is the cell the unscaled quotient gives.
-constexpr int kFineX = 4;        // a power of two
-constexpr int kFineRun = 5;      // quarters a probe's run spans
+#ifndef SVICP_FINEX
+#define SVICP_FINEX 4
+#endif
+constexpr int kFineX = SVICP_FINEX;     // a power of two (4: quarter cells; other values for A/B builds)
+constexpr int kFineRun = kFineX + 1;    // quarters a probe's run spans
+constexpr int kFineBits = kFineX == 1 ? 2 : kFineX == 2 ? 3 : kFineX == 4 ? 4 : 5;   // log2 of the quarters in a block's row
+static_assert((1 << kFineBits) == 4 * kFineX, "kFineX is 1, 2, 4 or 8");
 __device__ __forceinline__ bool probe_origin(const GridDesc &g, float qx, float qy, float qz,
                                              int &cx, int &cy, int &cz, int *cxq = nullptr)
 {
@@ -150,7 +180,7 @@ __device__ __forceinline__ bool probe_origin(const GridDesc &g, float qx, float 
 // Place of quarter cell (cxq, cy, cz) among the 256 of its block of 4 x 4 x 4 cells.
 __device__ __forceinline__ int quarter_local(int cxq, int cy, int cz)
 {
-    return ((cz & 3) << 6) | ((cy & 3) << 4) | (cxq & (4 * kFineX - 1));
+    return ((cz & 3) << (kFineBits + 2)) | ((cy & 3) << kFineBits) | (cxq & (4 * kFineX - 1));
 }
 
 // A probe record: the four runs {start, end} a probe from one quarter cell walks, run r in
@@ -253,7 +283,8 @@ __device__ __forceinline__ void scan_runs(const uint2 (&run)[4], float qx, float
 // the TOTAL candidate count, not the sum of per-run maxima.
 template <int CH, bool SECOND = false>
 __device__ __forceinline__ void nn_capped(const GridDesc &g, float qx, float qy, float qz,
-                                          float &best, int &bpos, int &bidx, float *second = nullptr)
+                                          float &best, int &bpos, int &bidx, float *second = nullptr,
+                                          const bool dropping = true)
 {
     best = INFINITY; bpos = -1; bidx = 0x7fffffff;
     if (SECOND) *second = INFINITY;
@@ -261,17 +292,29 @@ __device__ __forceinline__ void nn_capped(const GridDesc &g, float qx, float qy,
     if (!probe_origin(g, qx, qy, qz, cx, cy, cz, &cxq)) return;
 
     // run r covers the quarter cells cxq .. cxq + 4 of the row (cy + (r & 1), cz + (r >> 1))
-    const int rank = g.dir[dir_index(g, cx, cy, cz)];
+    const int rank = ((kDrop & kDropDir) && dropping) ? (cx + cy + cz) % max(g.m / 64, 1) : g.dir[dir_index(g, cx, cy, cz)];
     // an unranked block has no entry: read entry 0 of the table and drop it
     const size_t e = rank >= 0 ? (size_t)rank * (64 * kFineX) + quarter_local(cxq, cy, cz) : 0;
     uint2 run[4];
-    probe_runs(g, e, run);
+    if ((kDrop & (kDropQuad | kDropDir)) && dropping) {
+        // made-up runs of the usual lengths (2 + 2 + 2 + 2) at a place that depends on the query
+        const unsigned s0 = (unsigned)((cx * 7 + cy * 131 + cz * 977) & 0xffff);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) run[r] = make_uint2(s0 + 16u * r, s0 + 16u * r + 2u);
+    } else {
+        probe_runs(g, e, run);
+    }
     if (rank < 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) run[r] = make_uint2(0u, 0u);
     }
-    scan_runs<CH, SECOND>(run, qx, qy, qz, [&](unsigned j) { return g.pts[j]; }, best, bpos, bidx,
-                          second);
+    if ((kDrop & (kDropPts | kDropQuad | kDropDir)) && dropping)
+        scan_runs<CH, SECOND>(run, qx, qy, qz,
+                              [&](unsigned j) { return make_float4(qx + 0.001f * (float)(j & 1023u), qy, qz, __uint_as_float(j)); },
+                              best, bpos, bidx, second);
+    else
+        scan_runs<CH, SECOND>(run, qx, qy, qz, [&](unsigned j) { return g.pts[j]; }, best, bpos, bidx,
+                              second);
 }
 
 // The same search by one whole wave for ONE query (all lanes pass the same q): the
@@ -1038,7 +1081,10 @@ __device__ __forceinline__ void iterate_tile(
                            predicted, n_predicted);
         // while most tiles still have work the points move too far for the remembered
         // correspondences to be of use
-        prefetch = predicted && 4 * n_predicted <= nb;
+        // (only where this block's first wave solves: the early loads sit in the other arm of
+        // that branch.  With the solve in a launch of its own there is no such arm, and a
+        // block that took `prefetch` for done would go on with state it never loaded.)
+        prefetch = solve_now && predicted && 4 * n_predicted <= nb;
     }
     // Behind the flag rows: per tile the position of the last point of the tile that had to be
     // searched once the registration had settled.  Such points are near-ties that come back
@@ -1164,7 +1210,7 @@ __device__ __forceinline__ void iterate_tile(
             float mx = px[sl] - ox, my = py[sl] - oy, mz = pz[sl] - oz;
             m2[sl] = moved ? mx * mx + my * my + mz * mz : 0.f;
             // in place the store can be skipped for a point that did not move
-            if (live[sl] && (moved || !in_place)) {
+            if (live[sl] && (moved || !in_place) && !((kDrop & kDropSrcWrite) && iter == kDropIter)) {
                 const unsigned li = sl * kItThreads + threadIdx.x;
                 bx_out[li] = px[sl]; by_out[li] = py[sl]; bz_out[li] = pz[sl];
             }
@@ -1206,6 +1252,7 @@ __device__ __forceinline__ void iterate_tile(
         bool hopeless = true;
 #pragma unroll
         for (int sl = 0; sl < NP; ++sl) hopeless = hopeless && !(live[sl] && m2[sl] < cp.cov * cp.cov);
+        if (kLateState && iter <= kLateState) hopeless = true;
         if (__ballot(!hopeless) != 0ull) {
             if (!prefetch || wv == 0) {
 #pragma unroll
@@ -1277,6 +1324,7 @@ __device__ __forceinline__ void iterate_tile(
     SVICP_STAMP(5);
     // ---- G: search the queued points (CPoint2PlaneICP.cpp:65-67) ----
     // what a search found is remembered and, inside the threshold, accumulated
+    const bool dropping = kDrop != 0 && iter == kDropIter;
     auto settle = [&](const float4 &e, float best, int bpos, float second, auto &&target_point) {
         const unsigned li = (unsigned)__float_as_int(e.w);
         Float3 tp = { __int_as_float(0x7fc00000), 0.f, 0.f };   // NaN: no neighbour
@@ -1286,13 +1334,17 @@ __device__ __forceinline__ void iterate_tile(
         float lbn = cp.cov * kSlackDown * kSlackDown;
         if (bpos >= 0 && sqrtf(best) * kSlackUp <= cp.cov) {
             // no unprobed point can be nearer: bpos is the nearest neighbour
-            const float4 t = target_point();
+            const float4 t = ((kDrop & (kDropPts | kDropQuad | kDropDir)) && dropping)
+                                 ? make_float4(e.x + 0.5f, e.y, e.z, 0.f) : target_point();
             tp = { t.x, t.y, t.z };
-            nv = reinterpret_cast<const Float3 *>(g.nrm)[bpos];     // one 12-byte gather, not three of 4
+            if ((kDrop & kDropNrm) && dropping) nv = { 0.f, 0.6f, 0.8f };
+            else nv = reinterpret_cast<const Float3 *>(g.nrm)[bpos];     // one 12-byte gather, not three of 4
             lbn = fminf(sqrtf(second) * kSlackDown, lbn);
             if (best <= cp.thr)
                 accumulate_point(acc, e.x, e.y, e.z, best, cp.thr, t.x, t.y, t.z, nv.x, nv.y, nv.z);
         }
+        if ((kDrop & kDropStateWrite) && dropping) return;
+        if (kLateState && iter < kLateState) return;
         btp[li] = tp;
         bnv[li] = nv;
         blb[li] = lbn;
@@ -1323,7 +1375,7 @@ __device__ __forceinline__ void iterate_tile(
             const float4 f0 = found[q][0], f1 = found[q][1];
             t = f0; best = f0.w; second = f1.x; bpos = __float_as_int(f1.y);
         } else {
-            nn_capped<CH, true>(g, e.x, e.y, e.z, best, bpos, bidx, &second);
+            nn_capped<CH, true>(g, e.x, e.y, e.z, best, bpos, bidx, &second, dropping);
         }
         settle(e, best, bpos, second, [&]() { return few ? t : g.pts[bpos]; });
     }
@@ -1558,6 +1610,343 @@ __global__ void reset_state_kernel(IcpState *st)
     }
 }
 
+
+// ------------------------------------------------------------------------
+// Exact 1-NN far from the target: one candidate box per WAVE, staged in LDS.
+//
+// A query whose nearest target point lies beyond the probe radius has to look several cells
+// out, and thread by thread that is 50 to 200 candidates per query gathered lane by lane, behind
+// two table look-ups per row of cells.  But the 64 queries of a wave are neighbours (Morton
+// order), and so are the boxes around them: the wave takes ONE box around all its open queries,
+// copies the box's points into LDS once, and every lane runs over all staged points by broadcast
+// reads, with the same separately rounded distance and the same (distance, index) order as
+// everywhere else.
+//
+// The box is looked up block by block (4 x 4 x 4 cells): one directory word per block of the
+// box, all in one trip; only the blocks that hold points go on (a surface fills a fraction of a
+// box's blocks), each with its 16 rows of cells: a row's cells inside the box are one contiguous
+// stretch of the sorted target (a "piece": start and end from the block's cell table, one
+// more trip for all pieces of 4 blocks).  The pieces' points are dealt to the lanes 64 at a
+// time, so the copies are coalesced and all in flight together.
+//
+// A lane is settled when its best distance lies inside the sphere around ITS query that the
+// box is certain to contain (the test of ring_box, from the lane's own position); the others go
+// on with a box that reaches as far as the largest best distance among them (then every lane
+// settles), or, while some lane has found nothing at all, with a pad twice as wide.  Blocks
+// that lie inside the box of the round before are left out (their points have been seen).  What
+// the box cannot settle (too many blocks or points) is left to the caller's search by rings.
+// ------------------------------------------------------------------------
+constexpr int kFarCap = 256;            // points staged per wave and pass (4 KB)
+constexpr int kFarMinOpen = 8;          // open lanes from which a wave goes straight to the list
+constexpr int kFarMaxBlocks = 128;      // blocks of cells a box may have (more: the wave's queries are split up)
+constexpr int kFarMaxRanked = 32;       // blocks looked up at a time (a lane each), all of which may hold points
+constexpr int kFarMaxPieces = 16 * kFarMaxRanked;
+constexpr int kFarMaxPoints = 2560;     // points a box may hold (more: the wave's queries are split up)
+constexpr int kFarRounds = 6;
+#ifdef SVICP_FAR_STATS
+// development build: waves, rounds, blocks looked up, points staged, lanes entering, lanes settled,
+// give-ups, -, then the time (10 ns units) of the four phases; summed in registers and added to
+// the totals once, when a wave of nn1_far_kernel has finished all its work
+__device__ unsigned long long g_far_stats[16];
+struct FarCounters { unsigned long long v[12]; };
+#define SVICP_FAR_COUNT(k, val) do { fc.v[k] += (unsigned long long)(val); } while (0)
+#define SVICP_FAR_T(var) const unsigned long long var = wall_clock64()
+#else
+struct FarCounters { };
+#define SVICP_FAR_COUNT(k, val) do { } while (0)
+#define SVICP_FAR_T(var) do { } while (0)
+#endif
+
+__device__ __forceinline__ int wave_inclusive_max(int v);    // (defined with the k-NN kernels below)
+
+// Maximum / minimum over the 64 lanes, the same in every lane afterwards (moves inside rows of 16
+// lanes, then the row ends passed on: no LDS traffic).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or(float v, float outside)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(outside), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    v = fmaxf(v, dpp_or<0x111, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x112, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x114, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x118, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x142, 0xa>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x143, 0xc>(v, -INFINITY));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_min_f(float v) { return -wave_max_f(-v); }
+
+// A wave's working memory in LDS (8.8 KB).
+struct FarStage {
+    float4 xy[kFarCap / 2];              // pairs of points {x0, x1, y0, y1}: the operands of the packed arithmetic
+    float4 zw[kFarCap / 2];              //                 {z0, z1, index0, index1}
+    unsigned short heads[kFarCap];       // per place of a pass: 1 + the piece that starts there, or 0
+    unsigned piece_start[kFarMaxPieces]; // where a piece starts in the sorted target
+    unsigned short piece_len[kFarMaxPieces], piece_excl[kFarMaxPieces];   // its points, and the points before it
+    int2 ranked[kFarMaxRanked];          // {rank, block coordinates packed} of the blocks that hold points
+};
+
+// `open`: this lane has a finite query without a final answer.  On return `open` lanes that were
+// settled have done = true and their answer in best / bidx (bidx = -1: the target is empty).
+// Returns false when a box got too large (the open queries lie far apart: a wave that straddles
+// a jump of the Morton order); the caller then offers the lanes still open part by part.
+__device__ __forceinline__ bool far_search_wave(const GridDesc &g, float qx, float qy, float qz, bool open,
+                                                float &best, int &bidx, bool &done, FarStage &st, FarCounters &fc)
+{
+    const int lane = threadIdx.x & 63;
+    constexpr unsigned long long kNoKey = ((unsigned long long)0x7f800000u << 32) | 0xffffffffu;
+    unsigned long long bkey = kNoKey;
+    if (open && best < INFINITY && bidx >= 0)
+        bkey = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bidx;
+    // round 0: one cell around the queries' cells; two where most of the wave is open (a stretch
+    // of the source away from the target: one larger box then settles most lanes at once)
+    float pad = __popcll(__ballot(open)) >= 32 ? 2.0f * g.h : g.h;
+    const v2f q2x = { qx, qx }, q2y = { qy, qy }, q2z = { qz, qz };
+    // the box of the round before (all of it has been scanned): empty before the first
+    int ox0 = 0, ox1 = -1, oy0 = 0, oy1 = -1, oz0 = 0, oz1 = -1;
+    float *const sxy = reinterpret_cast<float *>(st.xy), *const szw = reinterpret_cast<float *>(st.zw);
+    SVICP_FAR_COUNT(0, 1);
+    for (int round = 0; round < kFarRounds; ++round) {
+        if (__ballot(open) == 0ull) return true;
+        SVICP_FAR_COUNT(1, 1);
+        // the box: cells that hold [lowest query - pad, highest query + pad] on every axis
+        const float lx = wave_min_f(open ? qx : INFINITY), hx = wave_max_f(open ? qx : -INFINITY);
+        const float ly = wave_min_f(open ? qy : INFINITY), hy = wave_max_f(open ? qy : -INFINITY);
+        const float lz = wave_min_f(open ? qz : INFINITY), hz = wave_max_f(open ? qz : -INFINITY);
+        auto cell = [&](float v, float o, int n) {
+            float f = (v - o) * g.inv_h;
+            f = fminf(fmaxf(f, 0.f), (float)(n - 1));
+            return (int)f;
+        };
+        // (never smaller than the box before)
+        int x0 = cell(lx - pad, g.ox, g.nx), x1 = cell(hx + pad, g.ox, g.nx);
+        int y0 = cell(ly - pad, g.oy, g.ny), y1 = cell(hy + pad, g.oy, g.ny);
+        int z0 = cell(lz - pad, g.oz, g.nz), z1 = cell(hz + pad, g.oz, g.nz);
+        if (ox1 >= ox0) {
+            x0 = min(x0, ox0); x1 = max(x1, ox1); y0 = min(y0, oy0); y1 = max(y1, oy1);
+            z0 = min(z0, oz0); z1 = max(z1, oz1);
+        }
+        const int bx0 = x0 >> 2, by0 = y0 >> 2, bz0 = z0 >> 2;
+        const int nbxs = (x1 >> 2) - bx0 + 1, nbys = (y1 >> 2) - by0 + 1, nbzs = (z1 >> 2) - bz0 + 1;
+        const int nblk = nbxs * nbys * nbzs;
+        if (nblk > kFarMaxBlocks) { SVICP_FAR_COUNT(6, 1); return false; }
+        SVICP_FAR_COUNT(2, nblk);
+        // the radius around this lane's query the box is certain to cover (as ring_box)
+        float rho = INFINITY;
+        if (x0 > 0) rho = fminf(rho, qx - (g.ox + (float)x0 * g.h));
+        if (x1 < g.nx - 1) rho = fminf(rho, (g.ox + (float)(x1 + 1) * g.h) - qx);
+        if (y0 > 0) rho = fminf(rho, qy - (g.oy + (float)y0 * g.h));
+        if (y1 < g.ny - 1) rho = fminf(rho, (g.oy + (float)(y1 + 1) * g.h) - qy);
+        if (z0 > 0) rho = fminf(rho, qz - (g.oz + (float)z0 * g.h));
+        if (z1 < g.nz - 1) rho = fminf(rho, (g.oz + (float)(z1 + 1) * g.h) - qz);
+        const bool whole_grid = rho == INFINITY;
+        if (!whole_grid) rho = rho * (1.0f - 1e-5f) - g.cov_slack;
+
+        // ---- the blocks of the box that hold points and do not lie inside the old box ----
+        // quotients by multiplication: (t + 0.5) / d is at least 0.5 / d from an integer and
+        // t < 2^9, d <= 2^9, so the reciprocal's rounding cannot carry it across one
+        const float inv_nbxs = __builtin_amdgcn_rcpf((float)nbxs), inv_nbys = __builtin_amdgcn_rcpf((float)nbys);
+        bool gave_up = false;
+        int seen = 0;
+        for (int bb = 0; bb < nblk && !gave_up; bb += kFarMaxRanked) {
+            SVICP_FAR_T(t0b);
+            wave_lds_sync();                              // (the batch before has read its tables)
+            const int t = lane < kFarMaxRanked ? bb + lane : nblk;
+            const int row = (int)(((float)t + 0.5f) * inv_nbxs);
+            const int bx = bx0 + t - row * nbxs;
+            const int zr = (int)(((float)row + 0.5f) * inv_nbys);
+            const int by = by0 + row - zr * nbys, bz = bz0 + zr;
+            int rank = -1;
+            if (t < nblk) {
+                // (a block all of whose cells in the new box lie in the old box was scanned then)
+                const bool inside_old = ox1 >= ox0 && max(bx * 4, x0) >= ox0 && min(bx * 4 + 3, x1) <= ox1 &&
+                                        max(by * 4, y0) >= oy0 && min(by * 4 + 3, y1) <= oy1 &&
+                                        max(bz * 4, z0) >= oz0 && min(bz * 4 + 3, z1) <= oz1;
+                if (!inside_old) rank = g.dir[(bz * g.nby + by) * g.nbx + bx];
+            }
+            const unsigned long long has = __ballot(rank >= 0);
+            const int nranked = __popcll(has);
+            if (rank >= 0)
+                st.ranked[__popcll(has & ((1ull << lane) - 1ull))] =
+                    make_int2(rank, (bx - bx0) | ((by - by0) << 10) | ((bz - bz0) << 20));   // (each below 512)
+            wave_lds_sync();
+            SVICP_FAR_COUNT(8, wall_clock64() - t0b);
+            if (nranked == 0) continue;
+            SVICP_FAR_T(t1);
+            // ---- pieces: the 16 rows of cells of every such block, clipped to the box; the loads of
+            // four groups of 64 pieces are in flight together ----
+            const int npieces = 16 * nranked;
+            int total = 0;
+            for (int pb = 0; pb < npieces; pb += 256) {
+                unsigned s4[4], e4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pc = pb + 64 * u + lane;
+                    s4[u] = 0; e4[u] = 0;
+                    if (pc < npieces) {
+                        const int2 blk = st.ranked[pc >> 4];
+                        const int cellrow = pc & 15;
+                        const int pbx = bx0 + (blk.y & 1023), pby = by0 + ((blk.y >> 10) & 1023), pbz = bz0 + (blk.y >> 20);
+                        const int y = pby * 4 + (cellrow & 3), z = pbz * 4 + (cellrow >> 2);
+                        if (y >= y0 && y <= y1 && z >= z0 && z <= z1) {
+                            int xa = max(x0, pbx * 4), xb = min(x1, pbx * 4 + 3);
+                            // the cells of this row the old box held have been scanned: cut them off
+                            // where they are at one end of the piece (a piece that reaches beyond
+                            // the old box on both sides is taken whole)
+                            if (ox1 >= ox0 && y >= oy0 && y <= oy1 && z >= oz0 && z <= oz1) {
+                                if (xa >= ox0) xa = max(xa, ox1 + 1);
+                                else if (xb <= ox1) xb = min(xb, ox0 - 1);
+                            }
+                            if (xa <= xb) {
+                                const int base = blk.x * 64 + (cellrow << 2);
+                                s4[u] = g.run2[base + (xa & 3)].x;
+                                e4[u] = g.end1[base + (xb & 3)];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pc = pb + 64 * u + lane;
+                    if (pb + 64 * u >= npieces) break;
+                    const int len = (int)(e4[u] - s4[u]);
+                    const int incl = wave_inclusive_scan(len);
+                    if (pc < npieces) {
+                        st.piece_start[pc] = s4[u];
+                        st.piece_len[pc] = (unsigned short)min(len, 65535);
+                        st.piece_excl[pc] = (unsigned short)min(total + incl - len, 65535);
+                    }
+                    total += __builtin_amdgcn_readlane(incl, 63);
+                }
+            }
+            seen += total;
+            if (total > 65535 || seen > kFarMaxPoints) { gave_up = true; break; }
+            SVICP_FAR_COUNT(3, total);
+            SVICP_FAR_COUNT(9, wall_clock64() - t1);
+
+            // ---- passes of kFarCap points: dealt to the lanes, staged, scanned ----
+            for (int base = 0; base < total; base += kFarCap) {
+                const int here = min(total - base, kFarCap);
+                SVICP_FAR_T(t2);
+                wave_lds_sync();            // the pass before has been read
+#pragma unroll
+                for (int c = 0; c < kFarCap / 64; ++c)
+                    if (c * 64 < here) st.heads[c * 64 + lane] = 0;
+                wave_lds_sync();
+                // every piece with points in this pass marks its first place there
+                for (int pc = lane; pc < npieces; pc += 64) {
+                    const int len = st.piece_len[pc], excl = st.piece_excl[pc];
+                    if (len > 0 && excl + len > base && excl < base + kFarCap)
+                        st.heads[max(excl - base, 0)] = (unsigned short)(pc + 1);
+                }
+                wave_lds_sync();
+                float4 pt[kFarCap / 64];
+                int piece_before = 0;
+#pragma unroll
+                for (int c = 0; c < kFarCap / 64; ++c) {
+                    if (c * 64 >= here) break;
+                    const int p = c * 64 + lane;
+                    const int h = max(wave_inclusive_max((int)st.heads[p]), piece_before);
+                    piece_before = __builtin_amdgcn_readlane(h, 63);
+                    const int pc = max(h - 1, 0);
+                    // (a place past the end reads its piece's first point again: dropped below)
+                    const unsigned src = st.piece_start[pc] + (unsigned)(p < here ? base + p - (int)st.piece_excl[pc] : 0);
+                    pt[c] = g.pts[src];
+                }
+#pragma unroll
+                for (int c = 0; c < kFarCap / 64; ++c) {
+                    if (c * 64 >= here) break;
+                    const int slot = c * 64 + lane, pr = slot >> 1, el = slot & 1;
+                    if (slot < here) {
+                        sxy[4 * pr + el] = pt[c].x; sxy[4 * pr + 2 + el] = pt[c].y;
+                        szw[4 * pr + el] = pt[c].z; szw[4 * pr + 2 + el] = pt[c].w;
+                    }
+                }
+                // fill the last group of four with points that win nothing
+                if (lane < 4) {
+                    const int slot = here + lane;
+                    if (slot < ((here + 3) & ~3)) {
+                        const int pr = slot >> 1, el = slot & 1;
+                        sxy[4 * pr + el] = INFINITY; sxy[4 * pr + 2 + el] = INFINITY;
+                        szw[4 * pr + el] = INFINITY; szw[4 * pr + 2 + el] = __uint_as_float(0xffffffffu);
+                    }
+                }
+                wave_lds_sync();
+                SVICP_FAR_COUNT(10, wall_clock64() - t2);
+                SVICP_FAR_T(t3);
+                for (int pr = 0; pr < (here + 1) / 2; pr += 2) {
+                    const float4 a0 = st.xy[pr], b0 = st.zw[pr], a1 = st.xy[pr + 1], b1 = st.zw[pr + 1];
+                    v2f dx = q2x - (v2f){ a0.x, a0.y }, dy = q2y - (v2f){ a0.z, a0.w }, dz = q2z - (v2f){ b0.x, b0.y };
+                    v2f d0 = dx * dx; d0 = d0 + dy * dy; d0 = d0 + dz * dz;
+                    dx = q2x - (v2f){ a1.x, a1.y }; dy = q2y - (v2f){ a1.z, a1.w }; dz = q2z - (v2f){ b1.x, b1.y };
+                    v2f d1 = dx * dx; d1 = d1 + dy * dy; d1 = d1 + dz * dz;
+                    unsigned long long k;
+                    k = ((unsigned long long)__float_as_uint(d0.x) << 32) | __float_as_uint(b0.z); bkey = k < bkey ? k : bkey;
+                    k = ((unsigned long long)__float_as_uint(d0.y) << 32) | __float_as_uint(b0.w); bkey = k < bkey ? k : bkey;
+                    k = ((unsigned long long)__float_as_uint(d1.x) << 32) | __float_as_uint(b1.z); bkey = k < bkey ? k : bkey;
+                    k = ((unsigned long long)__float_as_uint(d1.y) << 32) | __float_as_uint(b1.w); bkey = k < bkey ? k : bkey;
+                }
+                SVICP_FAR_COUNT(11, wall_clock64() - t3);
+            }
+        }
+        if (gave_up) { SVICP_FAR_COUNT(6, 1); return false; }
+        // who is settled: the best distance lies inside the sphere the box covers, or the box
+        // is the whole grid (then an empty answer is final too)
+        const bool found = (unsigned)(bkey >> 32) < 0x7f800000u;
+        const float bd = __uint_as_float((unsigned)(bkey >> 32));
+        if (open && (whole_grid || (found && rho > 0.f && bd <= rho * rho))) {
+            done = true; open = false;
+            best = found ? bd : INFINITY;
+            bidx = found ? (int)(unsigned)bkey : -1;
+        }
+        if (whole_grid) return true;
+        ox0 = x0; ox1 = x1; oy0 = y0; oy1 = y1; oz0 = z0; oz1 = z1;
+        // next box: as far as the farthest best distance among the open lanes (every one of them
+        // then settles); while some lane has seen no point at all, twice the pad
+        const bool blind = __ballot(open && !found) != 0ull;
+        const float reach = wave_max_f(open && found ? sqrtf(bd) : 0.f);
+        pad = blind ? 2.0f * pad : fmaxf(reach * (1.0f + 1e-4f) + 2.0f * g.cov_slack + 1e-3f * g.h, pad);
+        // (a box that reaches `reach` beyond every open query leaves rho >= reach for each)
+    }
+    return __ballot(open) == 0ull;      // (rounds used up with lanes still open: as a box too large)
+}
+
+// The exact search of one query by rings of cells around its probe origin, each lane for
+// itself (the best so far carries over; later rings scan only the shell around the box already
+// seen).  Returns false when no ring up to kMaxRing settles the query: the exhaustive pass then.
+__device__ __forceinline__ bool ring_search_lane(const GridDesc &g, float qx, float qy, float qz, float &best,
+                                                 int &bpos, int &bidx, const int max_ring = kMaxRing)
+{
+    int cx, cy, cz;
+    clamped_origin(g, qx, qy, qz, cx, cy, cz);
+    auto visit = [&](unsigned j, const float4 &p) {
+        float d = dist2(qx, qy, qz, p);
+        int id = __float_as_int(p.w);
+        if (better(d, id, best, bidx)) { best = d; bpos = (int)j; bidx = id; }
+    };
+    // the box of the previous ring (already scanned): empty before the first scan
+    int px0 = 0, px1 = -1, py0 = 0, py1 = -1, pz0 = 0, pz1 = -1;
+    for (int ring = 0; ring <= max_ring; ++ring) {
+        int x0, x1, y0, y1, z0, z1;
+        float rho = ring_box(g, qx, qy, qz, cx, cy, cz, ring, x0, x1, y0, y1, z0, z1);
+        if (px1 < px0) {
+            scan_box_points(g, x0, x1, y0, y1, z0, z1, visit);
+        } else {
+            if (z0 < pz0) scan_box_points(g, x0, x1, y0, y1, z0, pz0 - 1, visit);
+            if (z1 > pz1) scan_box_points(g, x0, x1, y0, y1, pz1 + 1, z1, visit);
+            if (y0 < py0) scan_box_points(g, x0, x1, y0, py0 - 1, pz0, pz1, visit);
+            if (y1 > py1) scan_box_points(g, x0, x1, py1 + 1, y1, pz0, pz1, visit);
+            if (x0 < px0) scan_box_points(g, x0, px0 - 1, py0, py1, pz0, pz1, visit);
+            if (x1 > px1) scan_box_points(g, px1 + 1, x1, py0, py1, pz0, pz1, visit);
+        }
+        px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;
+        if (rho == INFINITY || (bpos >= 0 && rho > 0.f && best <= rho * rho)) return true;
+    }
+    return false;
+}
+
 // ------------------------------------------------------------------------
 // Standalone 1-NN over the resident source (CKNNSearch::getKNeighbour with
 // k = 1, CKNNSearch.cpp:67-71).  EXACT = false: neighbours within the probe
@@ -1569,7 +1958,7 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
     GridDesc g, const float *__restrict__ qx_, const float *__restrict__ qy_,
     const float *__restrict__ qz_, const int *__restrict__ perm, int n, float thr,
     int *__restrict__ idx_out, float *__restrict__ d2_out, int *__restrict__ unresolved,
-    int *__restrict__ n_unresolved)
+    int *__restrict__ n_unresolved, int4 *__restrict__ far_list = nullptr, int *__restrict__ n_far = nullptr)
 {
     // Capped search: a block takes consecutive chunks of 256 queries, and the blocks of one
     // XCD (blockIdx % 8 equal) consecutive blocks' worth, so each XCD's L2 sees one stretch of
@@ -1582,14 +1971,19 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
                                   : (long long)xcd_contiguous((int)blockIdx.x, (int)gridDim.x) * per_block;
     const long long last = EXACT ? chunks : (first + per_block < chunks ? first + per_block : chunks);
     for (long long c = first; c < last; c += EXACT ? (long long)gridDim.x : 1) {
-        const long long i = c * kBlockThreads + threadIdx.x;
-        if (i >= n) break;
+        const long long i_raw = c * kBlockThreads + threadIdx.x;
+        // (the exact search keeps whole waves together: a lane past the end repeats the last
+        // query and writes nothing)
+        const bool inrange = i_raw < n;
+        if (!EXACT && !inrange) break;
+        const long long i = inrange ? i_raw : (long long)n - 1;
         float qx = qx_[i], qy = qy_[i], qz = qz_[i];
         float best; int bpos, bidx;
         nn_capped<CH>(g, qx, qy, qz, best, bpos, bidx);
         const long long o = perm ? perm[i] : i;
         if (!EXACT) {
             bool hit = bpos >= 0 && best <= thr;
+            if ((kDrop & kDropOut) && best != 12345.678f) continue;    // (the search stays alive)
             idx_out[o] = hit ? bidx : -1;
             d2_out[o] = hit ? best : INFINITY;
             continue;
@@ -1612,32 +2006,26 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
             }
         }
         bool done = bpos >= 0 && r0 > 0.f && best <= r0 * r0;
-        int cx, cy, cz;
-        clamped_origin(g, qx, qy, qz, cx, cy, cz);
-        auto visit = [&](unsigned j, const float4 &p) {
-            float d = dist2(qx, qy, qz, p);
-            int id = __float_as_int(p.w);
-            if (better(d, id, best, bidx)) { best = d; bpos = (int)j; bidx = id; }
-        };
-        // the box of the previous ring (already scanned): empty before the first scan
-        int px0 = 0, px1 = -1, py0 = 0, py1 = -1, pz0 = 0, pz1 = -1;
-        for (int ring = 0; ring <= kMaxRing && !done; ++ring) {
-            int x0, x1, y0, y1, z0, z1;
-            float rho = ring_box(g, qx, qy, qz, cx, cy, cz, ring, x0, x1, y0, y1, z0, z1);
-            // later rings scan only the shell around the box already seen
-            if (px1 < px0) {
-                scan_box_points(g, x0, x1, y0, y1, z0, z1, visit);
-            } else {
-                if (z0 < pz0) scan_box_points(g, x0, x1, y0, y1, z0, pz0 - 1, visit);
-                if (z1 > pz1) scan_box_points(g, x0, x1, y0, y1, pz1 + 1, z1, visit);
-                if (y0 < py0) scan_box_points(g, x0, x1, y0, py0 - 1, pz0, pz1, visit);
-                if (y1 > py1) scan_box_points(g, x0, x1, py1 + 1, y1, pz0, pz1, visit);
-                if (x0 < px0) scan_box_points(g, x0, px0 - 1, py0, py1, pz0, pz1, visit);
-                if (x1 > px1) scan_box_points(g, px1 + 1, x1, py0, py1, pz0, pz1, visit);
-            }
-            px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;
-            if (rho == INFINITY || (bpos >= 0 && rho > 0.f && best <= rho * rho)) done = true;
+        // Lanes without an answer.  A few of them in a wave (the usual case once the clouds are
+        // registered: the nearest point lies just beyond the probe radius): each looks one ring of
+        // cells further for itself.  Many (a stretch of the source away from the target), or
+        // whoever the next ring does not settle: the wave goes on the list of nn1_far_kernel,
+        // which searches one box of candidates for all its open lanes.
+        const bool finite = fabsf(qx) < INFINITY && fabsf(qy) < INFINITY && fabsf(qz) < INFINITY;
+        bool open = inrange && !done && finite && g.m > 0;
+        const bool listed = far_list != nullptr;
+        const bool few_open = __popcll(__ballot(open)) < kFarMinOpen;
+        if (open && (!listed || few_open)) {
+            done = ring_search_lane(g, qx, qy, qz, best, bpos, bidx, listed ? 1 : kMaxRing);
+            open = !done && listed;
         }
+        // (the list has an entry per wave of this kernel, at the wave's own place: nothing to count)
+        const unsigned long long open_mask = __ballot(open);
+        if (listed && (threadIdx.x & 63) == 0)
+            far_list[i_raw >> 6] = make_int4((int)(i_raw), (int)(unsigned)open_mask, (int)(unsigned)(open_mask >> 32), 0);
+        if (!inrange || open) continue;
+        // (not finite, or an empty target: nothing is nearest)
+        if (!done && listed) { done = true; bpos = -1; }
         if (done) {
             idx_out[o] = bpos >= 0 ? bidx : -1;
             d2_out[o] = bpos >= 0 ? best : INFINITY;
@@ -1646,6 +2034,79 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
             unresolved[slot] = (int)i;
         }
     }
+}
+
+// The waves nn1_kernel<true> put on its list: one wave here per listed wave there, the same 64
+// queries, of which those marked open share a candidate box (far_search_wave).  What the box does
+// not settle searches by rings, and what they do not settle goes to the exhaustive pass.
+constexpr int kFarThreads = 128;        // two waves, 17.5 KB of LDS
+// Where a box gets too large (the open queries lie far apart: a wave that straddles a jump of the
+// Morton order) the wave's open lanes go on the next list in `parts` parts of `part_lanes` Morton
+// neighbours each (16 x 4, then 4 x 1), for the next launch of this kernel, so that the parts are spread
+// over the GPU instead of being worked off one after the other by the wave that failed.  Without
+// a next list (the last launch: single queries) they go to the exhaustive pass.
+__global__ __launch_bounds__(kFarThreads, 4) void nn1_far_kernel(
+    GridDesc g, const float *__restrict__ qx_, const float *__restrict__ qy_,
+    const float *__restrict__ qz_, const int *__restrict__ perm, int n, const int4 *__restrict__ far_list,
+    const int *__restrict__ n_far, int far_capacity, int4 *__restrict__ next_list, int *__restrict__ n_next, int next_capacity,
+    int parts, int part_lanes, int *__restrict__ idx_out, float *__restrict__ d2_out,
+    int *__restrict__ unresolved, int *__restrict__ n_unresolved)
+{
+    constexpr int W = kFarThreads / 64;
+    __shared__ FarStage stage[W];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // (the first list has an entry per wave of the search kernel: no counter; a list that ran
+    // over was not written beyond its capacity)
+    const int count = n_far ? min(*n_far, far_capacity) : far_capacity;
+    FarCounters fc = {};
+    for (int w = (int)blockIdx.x * W + wv; w < count; w += (int)gridDim.x * W) {
+        const int4 entry = far_list[w];
+        const unsigned long long mask = (unsigned long long)(unsigned)entry.y | ((unsigned long long)(unsigned)entry.z << 32);
+        const long long i_raw = (long long)entry.x + lane;
+        const bool open = (mask >> lane) & 1ull;            // (open lanes are in range)
+        const long long i = i_raw < n ? i_raw : (long long)n - 1;
+        const float qx = qx_[i], qy = qy_[i], qz = qz_[i];
+        float best = INFINITY;
+        int bidx = -1;
+        bool done = false;
+        const bool ok = far_search_wave(g, qx, qy, qz, open, best, bidx, done, stage[wv], fc);
+        bool passed_on = false;
+        if (!ok && next_list) {
+            // the lanes still open, in four parts, to the next launch
+            const unsigned long long left = __ballot(open && !done);
+            // (`parts` parts of `part_lanes` lanes: the lanes this entry's mask can span)
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(n_next, parts);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (slot + parts <= next_capacity) {
+                passed_on = true;
+                if (lane < parts) {
+                    const int low = (int)(__ffsll((long long)mask) - 1) & ~(parts * part_lanes - 1);
+                    const unsigned long long span = (1ull << part_lanes) - 1ull;
+                    const unsigned long long m = left & (span << (low + lane * part_lanes));
+                    next_list[slot + lane] = make_int4(entry.x, (int)(unsigned)m, (int)(unsigned)(m >> 32), 0);
+                }
+            }
+        }
+        if (!open || (passed_on && !done)) continue;
+        int bpos = bidx >= 0 ? 0 : -1;
+        SVICP_FAR_COUNT(7, __popcll(__ballot(!done)));
+        // (what no box settled, down to a box of its own, lies far from every target point: the
+        // exhaustive pass takes it)
+        const long long o = perm ? perm[i] : i;
+        if (done) {
+            idx_out[o] = bpos >= 0 ? bidx : -1;
+            d2_out[o] = bpos >= 0 ? best : INFINITY;
+        } else {
+            int slot = atomicAdd(n_unresolved, 1);
+            unresolved[slot] = (int)i;
+        }
+    }
+#ifdef SVICP_FAR_STATS
+    // (SVICP_FAR_STATS = 2: the launches after the first only)
+    if (lane == 0 && (SVICP_FAR_STATS != 2 || n_far != nullptr))
+        for (int k = 0; k < 12; ++k) atomicAdd(&g_far_stats[k], fc.v[k]);
+#endif
 }
 
 // ------------------------------------------------------------------------
@@ -2425,9 +2886,8 @@ __global__ void fill_quarter_runs_kernel(GridDesc g, const unsigned long long *_
     const int rank = (int)(t / (64 * kFineX)), local = (int)(t % (64 * kFineX));
     const int b = block_of_rank[rank];
     const int bx = b % g.nbx, by = (b / g.nbx) % g.nby, bz = b / (g.nbx * g.nby);
-    const int cxq = bx * 4 * kFineX + (local & (4 * kFineX - 1)), cy = by * 4 + ((local >> 4) & 3),
-              cz = bz * 4 + (local >> 6);
-    static_assert(kFineX == 4, "the quarter's place in its block is taken apart by fixed shifts");
+    const int cxq = bx * 4 * kFineX + (local & (4 * kFineX - 1)), cy = by * 4 + ((local >> kFineBits) & 3),
+              cz = bz * 4 + (local >> (kFineBits + 2));
     const int nxq = g.nx * kFineX;
     unsigned s = 0, e = 0;
     if (cxq < nxq && cy < g.ny && cz < g.nz) {
@@ -2451,8 +2911,8 @@ __global__ void fill_quads_kernel(GridDesc g, const int *__restrict__ block_of_r
     const int rank = (int)(t / (64 * kFineX)), local = (int)(t % (64 * kFineX));
     const int b = block_of_rank[rank];
     const int bx = b % g.nbx, by = (b / g.nbx) % g.nby, bz = b / (g.nbx * g.nby);
-    const int cxq = bx * 4 * kFineX + (local & (4 * kFineX - 1)), cy = by * 4 + ((local >> 4) & 3),
-              cz = bz * 4 + (local >> 6);
+    const int cxq = bx * 4 * kFineX + (local & (4 * kFineX - 1)), cy = by * 4 + ((local >> kFineBits) & 3),
+              cz = bz * 4 + (local >> (kFineBits + 2));
     uint2 nb[4] = { qrun[t], make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u) };
     for (int r = 1; r < 4; ++r) {
         const int y = cy + (r & 1), z = cz + (r >> 1);
