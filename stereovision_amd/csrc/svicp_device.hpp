@@ -2007,16 +2007,16 @@ __global__ __launch_bounds__(kBlockThreads) void nn1_kernel(
         }
         bool done = bpos >= 0 && r0 > 0.f && best <= r0 * r0;
         // Lanes without an answer.  A few of them in a wave (the usual case once the clouds are
-        // registered: the nearest point lies just beyond the probe radius): each looks one ring of
-        // cells further for itself.  Many (a stretch of the source away from the target), or
-        // whoever the next ring does not settle: the wave goes on the list of nn1_far_kernel,
+        // registered: the nearest point lies just beyond the probe radius): each scans the whole
+        // 2 x 2 x 2 cells around its probe origin for itself (ring 0).  Many (a stretch of the source
+        // away from the target), or whoever ring 0 does not settle: the wave goes on the list of nn1_far_kernel,
         // which searches one box of candidates for all its open lanes.
         const bool finite = fabsf(qx) < INFINITY && fabsf(qy) < INFINITY && fabsf(qz) < INFINITY;
         bool open = inrange && !done && finite && g.m > 0;
         const bool listed = far_list != nullptr;
         const bool few_open = __popcll(__ballot(open)) < kFarMinOpen;
         if (open && (!listed || few_open)) {
-            done = ring_search_lane(g, qx, qy, qz, best, bpos, bidx, listed ? 1 : kMaxRing);
+            done = ring_search_lane(g, qx, qy, qz, best, bpos, bidx, listed ? 0 : kMaxRing);
             open = !done && listed;
         }
         // (the list has an entry per wave of this kernel, at the wave's own place: nothing to count)
