@@ -350,6 +350,20 @@ int svicp_kernel_times(svicp_ctx *ctx, double *fused_ms, double *solve_ms, int *
  * at options.coherent. */
 int svicp_search_counts(svicp_ctx *ctx, int capacity_rows, double *counts_out);
 
+/* Sources of 4096 tiles (of 1024 points) or more keep, per tile, the box its
+ * points lie in and the smallest change of a coordinate that fp32 would
+ * register; a launch whose R, T cannot move any point of the box by that much
+ * leaves the tile unread (its sums stand, as for a tile that was read and found
+ * unmoved).  Number of tiles left unread in each iteration of the last
+ * svicp_run (`iterations` entries, capacity_rows as for svicp_get_history; all
+ * zero for smaller sources).  No counterpart in the reference: a statistic for
+ * tests and tuning. */
+int svicp_tiles_left_unread(svicp_ctx *ctx, int capacity_rows, double *counts_out);
+
+/* on = 0: launches read every tile whatever its record says (the results are
+ * the same bits either way: for tests and A/B timings).  Default on. */
+int svicp_debug_use_tile_boxes(svicp_ctx *ctx, int on);
+
 /* The same two quantities per iteration over the last timed svicp_run:
  * `iterations` entries each.  Either pointer may be NULL. */
 int svicp_iteration_times(svicp_ctx *ctx, double *fused_ms_out, double *solve_ms_out);

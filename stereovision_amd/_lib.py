@@ -87,6 +87,8 @@ SYMBOLS = {
     "svicp_sizes": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "svicp_grid_info": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "svicp_search_counts": (C.c_int, [_ctx, C.c_int, _dp]),
+    "svicp_tiles_left_unread": (C.c_int, [_ctx, C.c_int, _dp]),
+    "svicp_debug_use_tile_boxes": (C.c_int, [_ctx, C.c_int]),
     "svicp_run_point2point": (C.c_int, [_ctx, C.c_int, _dp, C.POINTER(Info)]),
     "svicp_get_history_rt": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
     "svicp_batch_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.POINTER(C.c_void_p)]),

@@ -114,7 +114,8 @@ struct ScopedEvent {
 // history, the tiles' "had work" flags.  Sized for kEnqMaxIters iterations of a source of
 // kEnqMaxTiles tiles (1024 points each).
 // from this many tiles on (four rounds of blocks on 256 compute units) the solve gets a launch of its own
-constexpr int kSolveApartTiles = 4096;
+constexpr int kManyTiles = 4096;     // tiles from which a source counts as large (see launch_iteration)
+constexpr int kManyFromIteration = 4;
 constexpr int kEnqMaxIters = 128;
 constexpr int kEnqMaxTiles = 4194304 / kItTile;
 constexpr size_t enq_align(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -198,13 +199,15 @@ struct svicp_ctx {
     DevBuf sx0, sy0, sz0, wx, wy, wz, perm;
     DevBuf st_tp, st_nv, st_lb;   // per source point: matched target point, normal, bound
     DevBuf tile_flags;            // [kFlagRows][kFlagWords] 64-bit words: which tiles had work in the last iterations
+    DevBuf tile_box;              // sources of kManyTiles tiles or more: where each wave's points lie (PointState::box)
+    bool use_tile_box = true;     // (svicp_debug_use_tile_boxes: off for an A/B against launches that read every tile)
 
 
     // iteration loop
     DevBuf partials, totals, deltas, state, xhist, ihist;
     // fixed-point exponents of the 30 sums (see update_fixed_point) and what they are made from
     DevBuf fx_exp;
-    DevBuf rt_apart;               // R, T handed from a solve launch to the iteration launch (many-tile sources)
+    DevBuf rt_apart;               // 16 doubles: R, T handed from a solve launch to the iteration launch (large sources); 12..13: the two integers the ranks of a sharded run agree on
     int fx_host[kNumSums] = {};
     float tgt_maxabs = 0.f, nrm_maxabs = 1.f;
     int64_t total_points = 0;      // source points over ALL ranks of a sharded run (0: this context's own)
@@ -574,6 +577,7 @@ void launch_iteration(svicp_ctx *ctx, int k, const LoopBufs &b)
     ps.nv = ctx->st_nv.as<Float3>();
     ps.lb = ctx->st_lb.as<float>();
     ps.active = b.flags;
+    ps.box = ctx->use_tile_box ? ctx->tile_box.as<float4>() : nullptr;     // (null below kManyTiles tiles)
     float *wx = ctx->wx.as<float>(), *wy = ctx->wy.as<float>(), *wz = ctx->wz.as<float>();
     const float *x0 = ctx->sx0.as<float>(), *y0 = ctx->sy0.as<float>(), *z0 = ctx->sz0.as<float>();
     IcpState *state = b.state;
@@ -583,24 +587,43 @@ void launch_iteration(svicp_ctx *ctx, int k, const LoopBufs &b)
     double *partials = b.partials;
     const dim3 grid(ctx->nb), block(kItThreads);
     const int n = (int)ctx->n;
-    // Many thousands of tiles: the previous iteration's system is solved once, by a launch of
-    // its own, instead of by every block of every round (the tile that records is then the
-    // solve kernel's: the iteration kernel only reads R and T).
-    const bool apart = k >= 1 && ctx->nb >= kSolveApartTiles;
+    // Many thousands of tiles.  The launches that search most of their points (the first
+    // kManyFromIteration of a run: iteration 0 has nothing to go by, iteration 1 follows the
+    // first and largest step, and a registration from an unregistered pose needs a few more) run
+    // a block per tile, with the previous iteration's system solved once, by a launch of its own,
+    // instead of by every block of every round.  The later ones run one round of blocks, each
+    // working through several tiles (icp_iterate_many_kernel): most tiles have nothing to do
+    // then, and every round of blocks would cost the time a block needs to find that out.  Both
+    // kernels are right for any launch; the choice is a matter of time only (searching launches
+    // of the 16.8 M-point pair: 520/590/290/106 us against 640/725/365/152; settled ones 47
+    // against 22).
+    static const int many_from = getenv("SVICP_MANY_TILES") ? atoi(getenv("SVICP_MANY_TILES")) : kManyTiles;
+    static const int many_from_iter = getenv("SVICP_MANY_FROM_ITER") ? atoi(getenv("SVICP_MANY_FROM_ITER")) : kManyFromIteration;
+    const bool large = ctx->nb >= many_from;
+    const bool many = large && k >= many_from_iter;
+    const bool apart = large && !many && k >= 1;
+    unsigned long long *many_flags =
+        ctx->tile_box.p ? reinterpret_cast<unsigned long long *>(ctx->tile_box.as<float4>() + (size_t)kBoxRecord * ctx->nb) : nullptr;
+    static const int per_cu = getenv("SVICP_MANY_PER_CU") ? std::max(1, atoi(getenv("SVICP_MANY_PER_CU"))) : SVICP_MANY_OCC;
+    const int many_blocks = std::max(std::min(ctx->nb, ctx->num_cus * per_cu), cdiv(ctx->nb, kManyRounds));
     double *rt = ctx->rt_apart.as<double>();
     if (apart)
         hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, ctx->stream, tot, del, fx, state, xh, ih, k - 1,
                            (IcpState *)nullptr, (double *)nullptr, rt);
 #define SVICP_ITERATE(APPLY, CERTIFY, INPLACE, ix, iy, iz)                                        \
     do {                                                                                          \
-        if (apart)                                                                                \
+        if (many)                                                                                 \
+            hipLaunchKernelGGL((icp_iterate_many_kernel<APPLY, CERTIFY, 4, INPLACE>), dim3(many_blocks), block, 0, \
+                               ctx->stream, tot, del, fx, k, n, ctx->nb, many_flags, ps.tp, ps.nv, ps.lb, ps.box, ix, iy, iz, \
+                               wx, wy, wz, state, xh, ih, cp, partials, ctx->g_dev.as<GridDesc>()); \
+        else if (large)                                                                           \
             hipLaunchKernelGGL((icp_iterate_kernel<APPLY, CERTIFY, 4, INPLACE, true>), grid, block, 0, ctx->stream, \
-                               tot, del, fx, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, \
-                               xh, ih, cp, partials, ctx->g_dev.as<GridDesc>(), rt);              \
+                               tot, del, fx, k, n, many_flags, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, \
+                               xh, ih, cp, partials, ctx->g_dev.as<GridDesc>(), rt, ps.box);      \
         else                                                                                      \
             hipLaunchKernelGGL((icp_iterate_kernel<APPLY, CERTIFY, 4, INPLACE, false>), grid, block, 0, ctx->stream, \
                                tot, del, fx, k, n, ps.active, ps.tp, ps.nv, ps.lb, ix, iy, iz, wx, wy, wz, state, \
-                               xh, ih, cp, partials, ctx->g_dev.as<GridDesc>(), (const double *)nullptr); \
+                               xh, ih, cp, partials, ctx->g_dev.as<GridDesc>(), (const double *)nullptr, (float4 *)nullptr); \
     } while (0)
     // iteration 0 reads the source as set and moves nothing, iteration 1 reads it and writes
     // the moving copy, later ones update the moving copy where it is
@@ -788,7 +811,7 @@ int svicp_destroy(svicp_ctx *ctx)
     return_scratch_slot(ctx->device, ctx->enq_slot);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     DevBuf *bufs[] = { &ctx->pts, &ctx->nrm, &ctx->dir, &ctx->quad, &ctx->quad_big, &ctx->g_dev, &ctx->sx0, &ctx->sy0, &ctx->sz0, &ctx->wx,
-                       &ctx->wy, &ctx->wz, &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->tile_flags, &ctx->perm,
+                       &ctx->wy, &ctx->wz, &ctx->st_tp, &ctx->st_nv, &ctx->st_lb, &ctx->tile_flags, &ctx->tile_box, &ctx->perm,
                        &ctx->partials, &ctx->totals, &ctx->deltas, &ctx->state, &ctx->xhist, &ctx->ihist,
                        &ctx->p2p_sums, &ctx->rthist, &ctx->fx_exp, &ctx->rt_apart };
     for (DevBuf *b : bufs) b->release();          // (slices of an arena are the arena's to free)
@@ -1113,6 +1136,22 @@ int svicp_set_source(svicp_ctx *ctx, const float *xyz_aos, int64_t n)
         HIPCHK(ctx->st_tp.reserve(sizeof(float4) * nn));
         HIPCHK(ctx->st_nv.reserve(sizeof(Float3) * nn));
         if (ctx->st_tp.p != before_tp || ctx->st_nv.p != before_nv) drop_graph(ctx);
+        // a large source: per wave of every tile the box of its points, from which a launch
+        // late in the registration proves most tiles static without reading them
+        const int64_t tiles = cdiv(nn, (int64_t)kItTile);
+        if (tiles >= kManyTiles && !ctx->lean()) {
+            void *before_box = ctx->tile_box.p;
+            // (behind the records: three rows of a flag bit per tile, "had work in that launch")
+            const size_t records = sizeof(float4) * kBoxRecord * tiles, rows = sizeof(unsigned long long) * kFlagRows * cdiv(tiles, (int64_t)64);
+            HIPCHK(ctx->tile_box.reserve(records + rows));
+            if (ctx->tile_box.p != before_box) {
+                drop_graph(ctx);
+                HIPCHK(hipMemsetAsync(ctx->tile_box.as<char>() + records, 0, rows, ctx->stream));
+            }
+        } else if (ctx->tile_box.p) {
+            ctx->tile_box.release();
+            drop_graph(ctx);
+        }
     }
     HIPCHK(ctx->scr->tmp_aos.reserve(sizeof(float) * 3 * nn));
     ctx->n = n;
@@ -1383,6 +1422,35 @@ int svicp_search_counts(svicp_ctx *ctx, int capacity_rows, double *counts_out)
         for (int cp = 0; cp < kDeltaCopies; ++cp) c += (double)rows[(size_t)k * kDeltaRow + cp * kNumSums + 31];
         counts_out[k] = c;
     }
+    return SVICP_OK;
+}
+
+int svicp_tiles_left_unread(svicp_ctx *ctx, int capacity_rows, double *counts_out)
+{
+    if (!ctx || !counts_out) return fail(ctx, SVICP_ERR_ARG, "svicp_tiles_left_unread: NULL argument");
+    if (ctx->last_iters <= 0 || ctx->last_was_p2p)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_tiles_left_unread: no point-to-plane run yet");
+    if (capacity_rows < ctx->last_iters)
+        return fail(ctx, SVICP_ERR_ARG, "svicp_tiles_left_unread: capacity_rows is below the last run's iterations");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<fx_t> rows((size_t)kDeltaRow * ctx->last_iters);
+    HIPCHK(hipMemcpyAsync(rows.data(), ctx->deltas.p, sizeof(fx_t) * rows.size(),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    counts_out[0] = 0.0;      // (row 0 was cleared for the next run; iteration 0 reads every tile)
+    for (int k = 1; k < ctx->last_iters; ++k) {
+        double c = 0.0;
+        for (int cp = 0; cp < kDeltaCopies; ++cp) c += (double)rows[(size_t)k * kDeltaRow + cp * kNumSums + 30];
+        counts_out[k] = c;
+    }
+    return SVICP_OK;
+}
+
+int svicp_debug_use_tile_boxes(svicp_ctx *ctx, int on)
+{
+    if (!ctx) return SVICP_ERR_ARG;
+    if (ctx->use_tile_box != (on != 0)) drop_graph(ctx);
+    ctx->use_tile_box = on != 0;
     return SVICP_OK;
 }
 
@@ -1974,7 +2042,7 @@ int svicp_batch_create_from_arrays(int device_id, int count, const int64_t *tgt_
         if (opt) c->opt = *opt; else svicp_default_options(&c->opt);
         c->scr = &b->shared;
         DevBuf *persistent[] = { &c->pts, &c->nrm, &c->dir, &c->quad, &c->quad_big, &c->g_dev, &c->sx0, &c->sy0, &c->sz0, &c->wx, &c->wy,
-                                 &c->wz, &c->st_tp, &c->st_nv, &c->st_lb, &c->tile_flags, &c->perm, &c->partials,
+                                 &c->wz, &c->st_tp, &c->st_nv, &c->st_lb, &c->tile_flags, &c->tile_box, &c->perm, &c->partials,
                                  &c->totals, &c->deltas, &c->state, &c->xhist, &c->ihist, &c->p2p_sums,
                                  &c->rthist, &c->fx_exp, &c->rt_apart };
         for (DevBuf *d : persistent) d->arena = &b->arena;

@@ -658,9 +658,75 @@ struct PointState {
     // whether tile t had work to do in iteration k (see choose_tile).  A row is written in
     // iteration k (atomic OR by the tiles with work), read in k + 1 and cleared in k + 2.
     unsigned long long *active;
+    int flag_words = 64;          // words per row of `active` (64: the 4096 tiles choose_tile handles)
+    // [tiles][4 waves][kBoxWords] or null: where each wave's points lie (see box_cannot_move)
+    float4 *box = nullptr;
 };
 constexpr int kFlagCap = 4096;   // tiles the adaptive block order handles (64 per lane of a wave)
 constexpr int kFlagRows = 3, kFlagWords = kFlagCap / 64;
+
+// Maximum / minimum over the 64 lanes, the same in every lane afterwards (moves inside rows of 16
+// lanes, then the row ends passed on: no LDS traffic).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or(float v, float outside)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(outside), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    v = fmaxf(v, dpp_or<0x111, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x112, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x114, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x118, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x142, 0xa>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x143, 0xc>(v, -INFINITY));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_min_f(float v) { return -wave_max_f(-v); }
+
+// Per wave of a tile (64 x 4 points), two float4: {lowest x, y, z, -}, {highest x, y, z, -}; lowest
+// above highest (+inf, -inf) where the wave has nothing to say.
+// rounding_room(p): the step below which fl32(p + e) = p -- half a unit in the last place of p, a
+// quarter where p is a power of two (the floats below it lie half as far apart), nothing where p
+// is zero, tiny or not finite.  Over a set of coordinates of one sign the smallest room is that
+// of the smallest magnitude (a larger one in the same binade has a mantissa, hence the half
+// unit; in a higher binade even the quarter is as much).
+constexpr int kBoxWords = 2;
+constexpr int kBoxRecord = kBoxWords * 4;      // float4 per tile (256 threads: four waves)
+__device__ __forceinline__ float rounding_room(float p)
+{
+    const unsigned b = __float_as_uint(p);
+    const unsigned ex = b & 0x7f800000u;
+    if (ex < (27u << 23) || ex == 0x7f800000u) return 0.f;
+    return __uint_as_float(ex) * ((b & 0x007fffffu) ? 0x1p-24f : 0x1p-25f);
+}
+
+// Can no point inside the box [lo, hi] change under p <- fl32(R p + T)?  e = (R - I) p + T is
+// bounded over the box by interval arithmetic (signs kept: near convergence the rotation's and
+// the translation's shares cancel over most of the cloud, which a sum of magnitudes cannot see),
+// plus a slack of 2^-45 of the magnitudes involved for the roundings of the fp64 update and of
+// this test (each of a dozen operations errs by 2^-53 of its result); the point stays where it
+// is if that stays strictly inside the axis's room: that of the bound nearer to zero, and none
+// for a box that reaches across zero (the coordinates next to zero have next to no room anyway).
+// Anything not finite fails the comparison.
+__device__ __forceinline__ bool box_cannot_move(const float lo[3], const float hi[3], const double R[9], const double T[3])
+{
+    bool still = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double room = lo[a] > 0.f ? rounding_room(lo[a]) : hi[a] < 0.f ? rounding_room(hi[a]) : 0.f;
+        double mn = T[a], mx = T[a], mag = fabs(T[a]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double e = R[3 * a + j] - (a == j ? 1.0 : 0.0);
+            const double u = e * (double)lo[j], v = e * (double)hi[j];
+            mn += fmin(u, v); mx += fmax(u, v);
+            mag += fmax(fabs((double)lo[j]), fabs((double)hi[j]));      // |R| <= 1: the update's terms are no larger
+        }
+        still = still && (fmax(fabs(mn), fabs(mx)) + mag * 0x1p-45 < room);
+    }
+    return still;
+}
 
 // ------------------------------------------------------------------------
 // 6x6 solve and transform update on the device.
@@ -1034,13 +1100,34 @@ __device__ __forceinline__ int choose_tile(const unsigned long long bits, int nb
     return tile < nb ? tile : xcd_contiguous(b, nb);
 }
 
+#ifndef SVICP_TILE_OCC
+#define SVICP_TILE_OCC 4
+#endif
+#ifndef SVICP_MANY_OCC
+#define SVICP_MANY_OCC 3
+#endif
+// The block of tile 0 clears what the next iteration adds to: its delta row (the buffer holds
+// one row more than the longest run; row 0 is cleared by the kernel that ends a run) and the
+// flag row it will write (last read in the iteration before this one).
+__device__ __forceinline__ void start_next_rows(fx_t *__restrict__ deltas, unsigned long long *active,
+                                                int flag_words, int iter, int tile)
+{
+    if (tile != 0) return;
+    for (int k = threadIdx.x; k < kDeltaRow; k += kItThreads) deltas[(size_t)(iter + 1) * kDeltaRow + k] = 0;
+    if (active)
+        for (int w = threadIdx.x; w < flag_words; w += kItThreads)
+            active[(size_t)((iter + 1) % kFlagRows) * flag_words + w] = 0ull;
+}
+
 // The work of one block: tile `tile` of a source of `nb` tiles.
 // INPLACE: the coordinates are updated where they are read (s?_in are not looked at); else
 // s?_in and s?_out may still be the same arrays (the batch decides per launch).
 // solve_now = false: a kernel launched before this one has solved the previous iteration's
 // system and left R (9) and T (3) at rt_given (the batch does that: one solve per pair instead
 // of one per block).
-template <bool APPLY, bool CERTIFY, int CH, bool INPLACE = false>
+// BOXES: after the update every wave leaves the box of its points in ps.box (see box_cannot_move),
+// and the routine is ready to be called in a loop.
+template <bool APPLY, bool CERTIFY, int CH, bool INPLACE = false, bool BOXES = false>
 __device__ __forceinline__ void iterate_tile(
     const GridDesc &g, const float *sx_in_, const float *sy_in_, const float *sz_in_,
     float *sx_out, float *sy_out, float *sz_out, int n, fx_t *__restrict__ totals,
@@ -1057,7 +1144,15 @@ __device__ __forceinline__ void iterate_tile(
     __shared__ float4 found[kItThreads / 64][2];
     __shared__ __attribute__((aligned(16))) int wave_moved[kItThreads / 64];
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // BOXES: the routine runs in a loop over tiles.  It has no vector register to spare, and
+    // whatever it derives from the thread's number alone is the same for every tile: the
+    // compiler would work that out once, before the loop, and then has to park it in scratch
+    // memory (43 registers' worth, each reload a wait for memory in the middle of the routine).
+    // So the number passes through an empty asm statement per tile: nothing derived from it can
+    // be carried round the loop.
+    unsigned tid = threadIdx.x;
+    if (BOXES) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wv = tid >> 6;
     const float *const sx_in = INPLACE ? sx_out : sx_in_, *const sy_in = INPLACE ? sy_out : sy_in_,
                 *const sz_in = INPLACE ? sz_out : sz_in_;
     const bool in_place = INPLACE || sx_in == sx_out;
@@ -1103,7 +1198,7 @@ __device__ __forceinline__ void iterate_tile(
     float *const blb = ps.lb + tile0;
 
 #ifdef SVICP_TRACE
-    if (threadIdx.x == 0 && iter < kTraceIters && tile < kTraceTiles) {
+    if (tid == 0 && iter < kTraceIters && tile < kTraceTiles) {
         g_trace[((size_t)iter * kTraceTiles + tile) * kTraceStamps + 0] = t_entry;
         g_trace[((size_t)iter * kTraceTiles + tile) * kTraceStamps + 8] =
             __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
@@ -1111,25 +1206,19 @@ __device__ __forceinline__ void iterate_tile(
             __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
     }
 #endif
+    float4 *const boxes = BOXES && APPLY && ps.box ? ps.box + (size_t)tile * kBoxRecord : nullptr;
     // ---- A: coordinates (and the tile's old sums) are requested first, so
     // their latency runs under the solve ----
     float px[NP], py[NP], pz[NP];
     bool live[NP];
 #pragma unroll
     for (int sl = 0; sl < NP; ++sl) {
-        const unsigned li = sl * kItThreads + threadIdx.x;
+        const unsigned li = sl * kItThreads + tid;
         live[sl] = (int)li < tile_n;
         const unsigned lc = live[sl] ? li : 0u;
         px[sl] = bx_in[lc]; py[sl] = by_in[lc]; pz[sl] = bz_in[lc];
     }
-    // the next iteration's delta row starts at zero (the buffer holds one row more
-    // than the longest run; row 0 is cleared by the kernel that ends a run)
-    if (tile == 0) {
-        for (int k = threadIdx.x; k < kDeltaRow; k += kItThreads)
-            deltas[(size_t)(iter + 1) * kDeltaRow + k] = 0;
-        // and the flag row the next iteration will write (last read in the iteration before this one)
-        if (ps.active && threadIdx.x < kFlagWords) ps.active[((iter + 1) % kFlagRows) * kFlagWords + threadIdx.x] = 0ull;
-    }
+    start_next_rows(deltas, ps.active, ps.flag_words, iter, tile);
 
     // ---- B: the first wave solves the previous iteration's system.  Meanwhile, in a tile
     // that is expected to have work (it had some in the iteration before), the other waves
@@ -1165,13 +1254,13 @@ __device__ __forceinline__ void iterate_tile(
         } else if (CERTIFY && prefetch) {
 #pragma unroll
             for (int sl = 0; sl < NP; ++sl) {
-                const unsigned li = sl * kItThreads + threadIdx.x;
+                const unsigned li = sl * kItThreads + tid;
                 const unsigned lc = live[sl] ? li : 0u;
                 tp[sl] = btp[lc]; nv[sl] = bnv[lc]; lb[sl] = blb[lc];
             }
             // the first wave's share: per slot 64 points = 6 + 6 + 2 lines of 128 bytes (a few
             // more where the 768-byte stretches straddle lines: one touch every 96 bytes)
-            const int u = (int)threadIdx.x - 64;
+            const int u = (int)tid - 64;
             if (u < NP * 18) {
                 const int sl = u / 18, line = u % 18;
                 // a point every 8 records of 12 bytes, every 32 of 4; kept inside the tile at
@@ -1211,9 +1300,41 @@ __device__ __forceinline__ void iterate_tile(
             m2[sl] = moved ? mx * mx + my * my + mz * mz : 0.f;
             // in place the store can be skipped for a point that did not move
             if (live[sl] && (moved || !in_place) && !((kDrop & kDropSrcWrite) && iter == kDropIter)) {
-                const unsigned li = sl * kItThreads + threadIdx.x;
+                const unsigned li = sl * kItThreads + tid;
                 bx_out[li] = px[sl]; by_out[li] = py[sl]; bz_out[li] = pz[sl];
             }
+        }
+    }
+
+    // Where this wave's points lie now, for the next launches' proof that the tile stays put --
+    // but only once the wave has all but come to rest (no point moved by more than 2^-20 of its
+    // largest coordinate, some eight units in the last place): the steps shrink by a few per cent
+    // per iteration, so a wave that still moves farther will not be static in the next launch,
+    // and the launches that search, which are bound by their arithmetic, do not pay for six
+    // reductions per wave.  (A coordinate that is not finite fails the comparison as well.)
+    if (BOXES && APPLY && boxes) {
+        // (the first point of every lane first: in a launch that searches, that settles it)
+        bool at_rest = true;
+#pragma unroll
+        for (int sl = 0; sl < NP; ++sl) {
+            if (sl == 1 && __ballot(!at_rest) != 0ull) break;
+            const float big = fmaxf(fmaxf(fabsf(px[sl]), fabsf(py[sl])), fabsf(pz[sl])) * 0x1p-20f;
+            at_rest = at_rest && (!live[sl] || m2[sl] <= big * big);
+        }
+        float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
+        if (__ballot(!at_rest) == 0ull) {
+#pragma unroll
+            for (int sl = 0; sl < NP; ++sl)
+                if (live[sl]) {
+                    lox = fminf(lox, px[sl]); loy = fminf(loy, py[sl]); loz = fminf(loz, pz[sl]);
+                    hix = fmaxf(hix, px[sl]); hiy = fmaxf(hiy, py[sl]); hiz = fmaxf(hiz, pz[sl]);
+                }
+            lox = wave_min_f(lox); loy = wave_min_f(loy); loz = wave_min_f(loz);
+            hix = wave_max_f(hix); hiy = wave_max_f(hiy); hiz = wave_max_f(hiz);
+        }
+        if (lane == 0) {
+            boxes[wv * kBoxWords] = make_float4(lox, loy, loz, 0.f);
+            boxes[wv * kBoxWords + 1] = make_float4(hix, hiy, hiz, 0.f);
         }
     }
 
@@ -1257,14 +1378,14 @@ __device__ __forceinline__ void iterate_tile(
             if (!prefetch || wv == 0) {
 #pragma unroll
                 for (int sl = 0; sl < NP; ++sl) {
-                    const unsigned li = sl * kItThreads + threadIdx.x;
+                    const unsigned li = sl * kItThreads + tid;
                     const unsigned lc = live[sl] ? li : 0u;
                     tp[sl] = btp[lc]; nv[sl] = bnv[lc]; lb[sl] = blb[lc];
                 }
             }
 #pragma unroll
             for (int sl = 0; sl < NP; ++sl) {
-                const unsigned li = sl * kItThreads + threadIdx.x;
+                const unsigned li = sl * kItThreads + tid;
                 float lbn = lb[sl];
                 if (m2[sl] > 0.f) lbn = bound_after_move(lbn, m2[sl]);
                 const bool has = tp[sl].x == tp[sl].x;          // a neighbour is remembered
@@ -1365,7 +1486,7 @@ __device__ __forceinline__ void iterate_tile(
         }
         __syncthreads();
     }
-    for (int q = threadIdx.x; q < total; q += kItThreads) {
+    for (int q = tid; q < total; q += kItThreads) {
         const float4 e = queue[q];
         float best, second; int bpos, bidx;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1388,45 +1509,48 @@ __device__ __forceinline__ void iterate_tile(
     double old_row = 0.0;
     int exponent = 0;
     // (the threads that need the scaling are the lanes that asked for it with the sums)
-    if (threadIdx.x < 30) exponent = (APPLY && solve_now) ? sums.exponent : fx[threadIdx.x];
+    if (tid < 30) exponent = (APPLY && solve_now) ? sums.exponent : fx[tid];
     // (a tile's 32 sums lie together: one request of two lines)
-    if (APPLY && threadIdx.x < 30) old_row = partials[(size_t)tile * kNumSums + threadIdx.x];
+    if (APPLY && tid < 30) old_row = partials[(size_t)tile * kNumSums + tid];
     const double s = block_sum_30(acc, red);
-    if (threadIdx.x < 30) {
-        partials[(size_t)tile * kNumSums + threadIdx.x] = s;
+    if (tid < 30) {
+        partials[(size_t)tile * kNumSums + tid] = s;
         // both rows go to fixed point before they are subtracted: the totals are then the exact
         // integer sum of the tiles' current rows, whatever the order of the additions
         const fx_t d = to_fixed(s, exponent) - to_fixed(old_row, exponent);
         if (d != 0)
             atomicAdd(reinterpret_cast<unsigned long long *>(deltas) + (size_t)iter * kDeltaRow +
-                          (tile & (kDeltaCopies - 1)) * kNumSums + threadIdx.x,
+                          (tile & (kDeltaCopies - 1)) * kNumSums + tid,
                       (unsigned long long)d);
     }
     // slot 31 of the iteration's delta row counts the searched points (a statistic for the
     // caller; the solve reads slots 0..29 only).  Like every atomic of this kernel it is issued
     // after the wave's last load.
-    if (threadIdx.x == 31 && total > 0)
+    if (tid == 31 && total > 0)
         atomicAdd(reinterpret_cast<unsigned long long *>(deltas) + (size_t)iter * kDeltaRow +
                       (tile & (kDeltaCopies - 1)) * kNumSums + 31,
                   (unsigned long long)total);
-    if (ps.active && threadIdx.x == 64)
-        atomicOr(ps.active + (iter % kFlagRows) * kFlagWords + (tile >> 6), 1ull << (tile & 63));
+    if (ps.active && tid == 64)
+        atomicOr(ps.active + (size_t)(iter % kFlagRows) * ps.flag_words + (tile >> 6), 1ull << (tile & 63));
     // the first of the few points this tile had to search: where the next launch looks ahead
-    if (APPLY && CERTIFY && fixed_tile < 0 && few && total > 0 && threadIdx.x == 65) hints[tile] = queue[0];
+    if (APPLY && CERTIFY && fixed_tile < 0 && few && total > 0 && tid == 65) hints[tile] = queue[0];
     SVICP_STAMP(7);
 }
 
-// SOLVE_APART: a solve_kernel launched before this one has left R and T at rt_given (sources
-// of many thousands of tiles: their blocks run in many rounds, and a solve of 1.6 us in every
-// block of every round costs more than one more launch).
-template <bool APPLY, bool CERTIFY, int CH, bool INPLACE, bool SOLVE_APART = false>
-__global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
+// LARGE (sources of many thousands of tiles, in the launches that search most of their points;
+// see icp_iterate_many_kernel for the others): the blocks run in many rounds, and a solve of
+// 1.6 us in every block of every round costs more than one more launch, so a solve_kernel
+// launched before this one has left R and T at rt_given.  The blocks take their tiles in the
+// fixed order, and the flag rows (ps_active) are as long as the source needs.
+template <bool APPLY, bool CERTIFY, int CH, bool INPLACE, bool LARGE = false>
+__global__ __launch_bounds__(kItThreads, SVICP_TILE_OCC) void icp_iterate_kernel(
     // what the first loads of a launch need comes first
     fx_t *__restrict__ totals, fx_t *__restrict__ deltas, const int *__restrict__ fx, int iter, int n,
     unsigned long long *ps_active, Float3 *ps_tp, Float3 *ps_nv, float *ps_lb,   // a PointState, member by member
     const float *sx_in, const float *sy_in, const float *sz_in, float *sx_out, float *sy_out,
     float *sz_out, IcpState *st, double *X_hist, double *info_hist, CohParams cp,
-    double *__restrict__ partials, const GridDesc *__restrict__ grid, const double *__restrict__ rt_given)
+    double *__restrict__ partials, const GridDesc *__restrict__ grid, const double *__restrict__ rt_given,
+    float4 *ps_box)
 {
     // The target's grid is described in device memory, not in the kernel's arguments: only the
     // search reads it (scalar loads where it needs them), and thirty words fewer have to be
@@ -1435,12 +1559,173 @@ __global__ __launch_bounds__(kItThreads, 4) void icp_iterate_kernel(
     const int nb = (int)gridDim.x;
     PointState ps;
     ps.tp = ps_tp; ps.nv = ps_nv; ps.lb = ps_lb; ps.active = ps_active;
-    const bool adaptive = APPLY && CERTIFY && ps.active != nullptr;
-    iterate_tile<APPLY, CERTIFY, CH, INPLACE>(g, sx_in, sy_in, sz_in, sx_out, sy_out, sz_out, n,
-                                              totals, deltas, fx, st, X_hist, info_hist, iter, cp, ps,
-                                              partials,
-                                              adaptive ? -1 : xcd_contiguous((int)blockIdx.x, nb), nb,
-                                              /* solve_now = */ !SOLVE_APART, rt_given);
+    if (LARGE) { ps.flag_words = (nb + 63) >> 6; ps.box = ps_box; }
+    const bool adaptive = !LARGE && APPLY && CERTIFY && ps.active != nullptr;
+    iterate_tile<APPLY, CERTIFY, CH, INPLACE, LARGE>(g, sx_in, sy_in, sz_in, sx_out, sy_out, sz_out, n,
+                                                     totals, deltas, fx, st, X_hist, info_hist, iter, cp, ps,
+                                                     partials,
+                                                     adaptive ? -1 : xcd_contiguous((int)blockIdx.x, nb), nb,
+                                                     /* solve_now = */ !LARGE, rt_given);
+}
+
+// The same question for a tile, from the records its four waves left.
+__device__ __forceinline__ bool tile_cannot_move(const float4 *rec, const double *rt)
+{
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    bool all_said = true;
+#pragma unroll
+    for (int w = 0; w < kItThreads / 64; ++w) {
+        const float4 a = rec[w * kBoxWords], b = rec[w * kBoxWords + 1];
+        // (a wave without live points leaves (+inf, -inf) too: at the end of the source only,
+        // where the tile is then read)
+        all_said = all_said && a.x <= b.x;
+        lo[0] = fminf(lo[0], a.x); lo[1] = fminf(lo[1], a.y); lo[2] = fminf(lo[2], a.z);
+        hi[0] = fmaxf(hi[0], b.x); hi[1] = fmaxf(hi[1], b.y); hi[2] = fmaxf(hi[2], b.z);
+    }
+    double R[9], T[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = rt[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) T[k] = rt[9 + k];
+    return all_said && box_cannot_move(lo, hi, R, T);
+}
+
+// Sources of many thousands of tiles.  A block per tile runs such a source in many rounds of
+// resident blocks, and late in a registration, when most tiles have nothing to do, every round
+// still costs the few microseconds a block needs to find that out (16 rounds: 47 us for the
+// 16.8 M-point pair, unchanged when 96 % of the tiles were not even read).  Here the launch is
+// one round of blocks, each of which solves once and then works through several tiles:
+//  * the tiles that had work in the launch before (a flag bit each, as for choose_tile) are
+//    dealt out in turn -- the j-th of them to block j mod blocks -- because the work that is left
+//    late in a registration sits in runs and at power-of-two strides of the sorted source, and
+//    a block with several such tiles does them one after the other (8 to 10 us each);
+//  * every other tile belongs to a fixed block (tile r * blocks + b, turned by an odd number per
+//    round), which as a rule proves from the tile's box record that it cannot have moved.  While
+//    the first wave solves, the second reads the flags and the others fetch the box records of
+//    the block's fixed share, so that none of this costs a trip to memory per tile.
+// Whatever the flags say, every tile is worked on exactly once: by the block it is dealt to if
+// its bit is set, by its fixed block if not (the row is not written during the launch).
+constexpr int kManyRounds = 32;
+constexpr int kManyFlagWords = 512;     // flag words kept in LDS: 32768 tiles (beyond: fixed shares only)
+constexpr int kManyTurn = 173;
+__device__ __forceinline__ int many_tile(int first, int round, int blocks, int share)
+{
+    (void)blocks;
+    return first * share + round;
+}
+
+template <bool APPLY, bool CERTIFY, int CH, bool INPLACE>
+__global__ __launch_bounds__(kItThreads, SVICP_MANY_OCC) void icp_iterate_many_kernel(
+    fx_t *__restrict__ totals, fx_t *__restrict__ deltas, const int *__restrict__ fx, int iter, int n, int nb,
+    unsigned long long *ps_active, Float3 *ps_tp, Float3 *ps_nv, float *ps_lb, float4 *ps_box,
+    const float *sx_in, const float *sy_in, const float *sz_in, float *sx_out, float *sy_out,
+    float *sz_out, IcpState *st, double *X_hist, double *info_hist, CohParams cp,
+    double *__restrict__ partials, const GridDesc *__restrict__ grid)
+{
+    __shared__ double rt[12];
+    __shared__ float4 records[kManyRounds][kBoxRecord];
+    __shared__ unsigned long long flags[kManyFlagWords];
+    __shared__ int dealt[kManyRounds];
+    __shared__ int n_dealt_shared;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int words = (nb + 63) >> 6;
+    const int blocks = (int)gridDim.x;
+    const int first = xcd_contiguous((int)blockIdx.x, blocks);
+    const int share = (nb + blocks - 1) / blocks;
+    const int rounds = max(0, min(min(share, nb - first * share), kManyRounds));
+    const bool provable = APPLY && CERTIFY && INPLACE && ps_box != nullptr;
+    const bool dealing = APPLY && ps_active != nullptr && words <= kManyFlagWords;
+    if (APPLY) {
+        if (wv == 0) {
+            const SumsInFlight sums = request_sums(totals + (size_t)(iter - 1) * kNumSums,
+                                                   deltas + (size_t)(iter - 1) * kDeltaRow, fx);
+            solve_and_update(sums, totals + (size_t)iter * kNumSums, st, X_hist, info_hist, iter - 1,
+                             blockIdx.x + 1 == gridDim.x, rt);
+        } else if (wv == 1) {
+            if (dealing) {
+                // lane L looks after `per` consecutive words of the row the launch before wrote
+                const unsigned long long *row = ps_active + (size_t)((iter - 1) % kFlagRows) * words;
+                const int per = (words + 63) >> 6;
+                int cnt = 0;
+                for (int q = 0; q < per; ++q) {
+                    const int w = lane * per + q;
+                    const unsigned long long f = w < words ? row[w] : 0ull;
+                    if (w < words) flags[w] = f;
+                    cnt += __popcll(f);
+                }
+                const int inc = wave_inclusive_scan(cnt), excl = inc - cnt;
+                if (lane == 0) n_dealt_shared = 0;
+                // Of the tiles with a bit, counted through the row, this block has number me,
+                // me + blocks, ...  While there are more of them than blocks, me follows the order
+                // that keeps neighbouring tiles on one XCD (and its L2 on one stretch of the
+                // target); once they fit into one round it is the block's own number, which the
+                // dispatcher spreads over XCDs and compute units in turn -- in the other order
+                // 679 tiles with work filled five XCDs four blocks deep and left three idle.
+                const int with_work = __builtin_amdgcn_readlane(inc, 63);
+                const int me = with_work <= blocks ? (int)blockIdx.x : first;
+                for (int j = excl + ((me - excl) % blocks + blocks) % blocks; j < inc; j += blocks) {
+                    int m = j - excl, tile = -1;
+                    for (int q = 0; q < per && tile < 0; ++q) {
+                        const unsigned long long f = flags[lane * per + q];
+                        const int c = __popcll(f);
+                        if (m < c) tile = 64 * (lane * per + q) + select64(f, m);
+                        m -= c;
+                    }
+                    const int slot = atomicAdd(&n_dealt_shared, 1);
+                    if (slot < kManyRounds) dealt[slot] = tile;
+                }
+            }
+        } else if (provable) {
+            for (int w = (int)threadIdx.x - 128; w < rounds * kBoxRecord; w += kItThreads - 128) {
+                const int r = w / kBoxRecord;
+                records[r][w % kBoxRecord] = ps_box[(size_t)many_tile(first, r, blocks, share) * kBoxRecord + w % kBoxRecord];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the fixed share: lane r of every wave looks at tile r of it (every wave for itself, so
+    // that the answer needs no further barrier).  A tile is left alone if it was dealt to some
+    // block, or if its records prove that it stays where it is: what the tile routine would find
+    // out from the coordinates (its step D) is known here without them -- once most of a large
+    // cloud has stopped moving, reading coordinates is all such a launch would still do. ----
+    bool mine_to_do = false, proven = false;
+    if (lane < rounds) {
+        const int t = many_tile(first, lane, blocks, share);
+        const bool is_dealt = dealing && ((flags[t >> 6] >> (t & 63)) & 1ull);
+        proven = !is_dealt && provable && tile_cannot_move(records[lane], rt);
+        mine_to_do = !is_dealt && !proven;
+    }
+    const unsigned todo = (unsigned)__ballot(mine_to_do), n_proven = (unsigned)__popcll(__ballot(proven));
+    // (what steers the loop is the same in every lane: told to the compiler, so that it lives in
+    // scalar registers -- the tile routine needs every vector register it can get)
+    const int n_dealt = dealing ? __builtin_amdgcn_readfirstlane(min(n_dealt_shared, kManyRounds)) : 0;
+    const int n_todo = __popc(todo);
+    PointState ps;
+    ps.tp = ps_tp; ps.nv = ps_nv; ps.lb = ps_lb; ps.active = ps_active; ps.flag_words = words; ps.box = ps_box;
+    // tile 0 may be among the proven ones: what its block does for the next launch is done here
+    if (first == 0 && ((todo & 1u) == 0u) && !(dealing && (flags[0] & 1ull)))
+        start_next_rows(deltas, ps_active, words, iter, 0);
+    for (int i = 0; i < n_dealt + n_todo; ++i) {
+        int tile;
+        if (i < n_dealt) {
+            tile = __builtin_amdgcn_readfirstlane(dealt[i]);
+        } else {
+            // the (i - n_dealt)-th set bit of todo
+            unsigned m = todo;
+            for (int k = n_dealt; k < i; ++k) m &= m - 1u;
+            tile = many_tile(first, __ffs(m) - 1, blocks, share);
+        }
+        iterate_tile<APPLY, CERTIFY, CH, INPLACE, true>(*grid, sx_in, sy_in, sz_in, sx_out, sy_out, sz_out, n,
+                                                        totals, deltas, fx, st, X_hist, info_hist, iter, cp, ps,
+                                                        partials, tile, nb, /* solve_now = */ false, rt);
+        __syncthreads();          // (the next tile uses the same shared arrays)
+    }
+    // slot 30 of the iteration's delta row counts the tiles left unread (a statistic for the
+    // caller, like the searched points in slot 31)
+    if (APPLY && threadIdx.x == 0 && n_proven > 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(deltas) + (size_t)iter * kDeltaRow +
+                      (blockIdx.x & (kDeltaCopies - 1)) * kNumSums + 30,
+                  (unsigned long long)n_proven);
 }
 
 // ------------------------------------------------------------------------
@@ -1658,25 +1943,6 @@ struct FarCounters { };
 #endif
 
 __device__ __forceinline__ int wave_inclusive_max(int v);    // (defined with the k-NN kernels below)
-
-// Maximum / minimum over the 64 lanes, the same in every lane afterwards (moves inside rows of 16
-// lanes, then the row ends passed on: no LDS traffic).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_or(float v, float outside)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(outside), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ float wave_max_f(float v)
-{
-    v = fmaxf(v, dpp_or<0x111, 0xf>(v, -INFINITY));
-    v = fmaxf(v, dpp_or<0x112, 0xf>(v, -INFINITY));
-    v = fmaxf(v, dpp_or<0x114, 0xf>(v, -INFINITY));
-    v = fmaxf(v, dpp_or<0x118, 0xf>(v, -INFINITY));
-    v = fmaxf(v, dpp_or<0x142, 0xa>(v, -INFINITY));
-    v = fmaxf(v, dpp_or<0x143, 0xc>(v, -INFINITY));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ float wave_min_f(float v) { return -wave_max_f(-v); }
 
 // A wave's working memory in LDS (8.8 KB).
 struct FarStage {

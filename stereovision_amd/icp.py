@@ -230,6 +230,13 @@ class Context:
         self._check(self._lib.svicp_search_counts(self._h, iters, _dp(out)))
         return out
 
+    def tiles_left_unread(self):
+        """Tiles left unread per iteration of the last run() (large sources only)."""
+        iters = self.last_iterations()
+        out = np.zeros(iters, np.float64)
+        self._check(self._lib.svicp_tiles_left_unread(self._h, iters, _dp(out)))
+        return out
+
     def correspondences(self):
         _, n = self.sizes()
         idx = np.empty(n, np.int32)

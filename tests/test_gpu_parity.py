@@ -266,6 +266,37 @@ def test_coherent_search_matches_full_search(ctx, pair):
     ctx.set_options(coherent=1)
 
 
+def test_large_source_leaves_settled_tiles_unread(ctx):
+    """4096 tiles (the smallest source that counts as large): the launches from the fifth on run
+    one round of blocks that work through several tiles each, deal out the tiles that had work in
+    the launch before and leave unread those whose box records prove that no point of them can
+    change.  With the proofs switched off every tile is read; the results must be the same
+    bits, and agree with a run that searches every point in every iteration."""
+    from stereovision_amd import synth
+    tgt, nrm, src, P = synth.make_pair(2048, inlier_frac=0.7)
+    assert (len(src) + 1023) // 1024 >= 4096
+    ctx.set_target(tgt, nrm)
+    res = []
+    for boxes, coherent in ((1, 1), (0, 1), (1, 0)):
+        ctx._check(ctx._lib.svicp_debug_use_tile_boxes(ctx._h, boxes))
+        ctx.set_options(coherent=coherent)
+        ctx.set_source(src)
+        T, info = ctx.run(24)
+        X, I = ctx.history()
+        res.append((T, X, I, ctx.get_source(), ctx.search_counts(), ctx.tiles_left_unread()))
+    ctx._check(ctx._lib.svicp_debug_use_tile_boxes(ctx._h, 1))
+    ctx.set_options(coherent=1)
+    on, off, full = res
+    tiles = (len(src) + 1023) // 1024
+    assert on[5][:4].max() == 0 and on[5][-1] > 0.8 * tiles and off[5].max() == 0 and full[5].max() == 0
+    for a, b in zip(on[:5], off[:5]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert np.abs(on[0] @ P - np.eye(4)).max() < 5e-4
+    assert np.abs(on[1] - full[1]).max() < 1e-10 and np.abs(on[0] - full[0]).max() < 1e-10
+    assert np.array_equal(on[2][:, 0], full[2][:, 0])
+    assert ((on[3] == full[3]).all(axis=1)).mean() > 0.999
+
+
 # ---------------------------------------------------------------- synthetic
 @pytest.mark.parametrize("side", [32, 100, 256])
 def test_synthetic_pair_matches_oracle(ctx, po, side):

@@ -172,10 +172,13 @@ def test_shard_run_with_one_rank_communicator_equals_run(po):
 
 
 def test_config3_pair_registers_through_shard_run():
-    """The 16.8 M-point pair of the sharded configuration (16 384 tiles: the flag rows are out of
-    use and the solve has a launch of its own), 30 iterations through svicp_shard_run with a
-    one-rank communicator: it must arrive at its generating pose, with nearly every point
-    matched, and a second run must give the same bits."""
+    """The 16.8 M-point pair of the sharded configuration (16 384 tiles: the first launches run a
+    block per tile with the solve in a launch of its own, the later ones a round of blocks that
+    work through several tiles and leave unread the tiles whose box records prove that they stay
+    put), 30 iterations through svicp_shard_run with a one-rank communicator: it must arrive at
+    its generating pose, with nearly every point matched, and a second run must give the same
+    bits.  The same bits again with the proofs switched off, and the result of a run that
+    searches every point in every iteration (coherent = 0)."""
     import stereovision_amd as sv
     from stereovision_amd import synth
     from stereovision_amd.sharded import init_comm, run_sharded_native
@@ -190,7 +193,30 @@ def test_config3_pair_registers_through_shard_run():
         assert info.inliers > 0.98 * len(src)
         counts = ctx.search_counts()
         assert counts[0] == len(src) and counts[-1] < 1000
+        unread = ctx.tiles_left_unread()
+        tiles = (len(src) + 1023) // 1024
+        assert unread[0] == 0 and unread[1] == 0 and unread[-1] > 0.9 * tiles
+        X, I = ctx.history()
+        moved = ctx.get_source()
         ctx.set_source(src)
         T2, info2 = run_sharded_native(ctx, 30)
         assert np.array_equal(T, T2) and info2.inliers == info.inliers
         ctx.comm_destroy()
+        # every tile read in every launch: the same bits
+        ctx._check(ctx._lib.svicp_debug_use_tile_boxes(ctx._h, 0))
+        ctx.set_source(src)
+        T3, info3 = ctx.run(30)
+        X3, I3 = ctx.history()
+        assert ctx.tiles_left_unread().max() == 0
+        assert np.array_equal(T, T3) and np.array_equal(X, X3) and np.array_equal(I, I3)
+        assert np.array_equal(moved.view(np.uint32), ctx.get_source().view(np.uint32))
+        assert np.array_equal(counts, ctx.search_counts())
+        ctx._check(ctx._lib.svicp_debug_use_tile_boxes(ctx._h, 1))
+        # and a full search of every point in every iteration
+        ctx.set_options(coherent=0)
+        ctx.set_source(src)
+        T4, info4 = ctx.run(30)
+        X4, I4 = ctx.history()
+        assert np.abs(X - X4).max() < 1e-10 and np.abs(T - T4).max() < 1e-10
+        assert np.array_equal(I[:, 0], I4[:, 0])
+        assert ((moved == ctx.get_source()).all(axis=1)).mean() > 0.999

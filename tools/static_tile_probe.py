@@ -24,17 +24,6 @@ def morton_tiles(p):
     return np.argsort(key, kind="stable")
 
 
-side = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-tgt, nrm, src, P = synth.make_pair(side, inlier_frac=0.7 if side > 1024 else None)
-c = sv.Context(0)
-c.set_target(tgt, nrm)
-order = morton_tiles(src)
-iters_before = 12
-c.set_source(src)
-c.run(iters_before)            # source now moved iters_before - 1 times
-cur = c.get_source()
-
-
 def rt_of(x):
     a, b, g = x[:3]
     Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
@@ -43,23 +32,36 @@ def rt_of(x):
     return Rz @ Ry @ Rx, np.array(x[3:6])
 
 
-for k in range(iters_before, iters_before + 6):
-    # apply one more iteration through the library and compare bits
-    c.set_source(cur)
-    c.run(2)                   # moves the source once (by the first solve's R, T)
-    nxt = c.get_source()
-    Xh, _ = c.history()
-    Rk, Tk = rt_of(Xh[0])
-    moved = (nxt.view(np.uint32) != cur.view(np.uint32)).any(1)
-    n = len(cur) // 1024 * 1024
-    pt = cur[order[:n]].reshape(-1, 1024, 3).astype(np.float64)
-    mv = moved[order[:n]].reshape(-1, 1024).any(1)
-    mx = np.abs(pt).max(1); mnn = np.abs(pt).min(1)
-    E = np.abs(Rk - np.eye(3))
-    d = mx @ E.T + np.abs(Tk)[None, :]
-    with np.errstate(divide="ignore"):
-        half_ulp = np.where(mnn > 0, 2.0 ** (np.floor(np.log2(np.maximum(mnn, 1e-300))) - 24), 0.0)
-    ok = (d < half_ulp * 0.5).all(1)           # quarter ulp: safe at powers of two
-    print(f"iter {k}: |E| max {E.max():.2e} |T| {np.abs(Tk).max():.2e} d max per axis {d.max(0)}; "
-          f"tiles {len(mv)} really moving {mv.mean():.3f} provable {ok.mean():.3f} provable-and-moving {(ok & mv).sum()}")
-    cur = nxt
+
+if __name__ == "__main__":
+    side = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    tgt, nrm, src, P = synth.make_pair(side, inlier_frac=0.7 if side > 1024 else None)
+    c = sv.Context(0)
+    c.set_target(tgt, nrm)
+    order = morton_tiles(src)
+    iters_before = 12
+    c.set_source(src)
+    c.run(iters_before)            # source now moved iters_before - 1 times
+    cur = c.get_source()
+
+
+    for k in range(iters_before, iters_before + 6):
+        # apply one more iteration through the library and compare bits
+        c.set_source(cur)
+        c.run(2)                   # moves the source once (by the first solve's R, T)
+        nxt = c.get_source()
+        Xh, _ = c.history()
+        Rk, Tk = rt_of(Xh[0])
+        moved = (nxt.view(np.uint32) != cur.view(np.uint32)).any(1)
+        n = len(cur) // 1024 * 1024
+        pt = cur[order[:n]].reshape(-1, 1024, 3).astype(np.float64)
+        mv = moved[order[:n]].reshape(-1, 1024).any(1)
+        mx = np.abs(pt).max(1); mnn = np.abs(pt).min(1)
+        E = np.abs(Rk - np.eye(3))
+        d = mx @ E.T + np.abs(Tk)[None, :]
+        with np.errstate(divide="ignore"):
+            half_ulp = np.where(mnn > 0, 2.0 ** (np.floor(np.log2(np.maximum(mnn, 1e-300))) - 24), 0.0)
+        ok = (d < half_ulp * 0.5).all(1)           # quarter ulp: safe at powers of two
+        print(f"iter {k}: |E| max {E.max():.2e} |T| {np.abs(Tk).max():.2e} d max per axis {d.max(0)}; "
+              f"tiles {len(mv)} really moving {mv.mean():.3f} provable {ok.mean():.3f} provable-and-moving {(ok & mv).sum()}")
+        cur = nxt
