@@ -539,10 +539,12 @@ def main():
         # central differences need: 13 geometric stages (12 multiply-adds of the 3 x 4 product,
         # two quotients, r: 26 operations), 31 pixel stages (distortion polynomial, tangential
         # terms, intrinsics: 36), 30 central differences (a subtraction and a quotient each), the
-        # residual, and two rank-1 updates of the 16 x 16 Gram matrix on the matrix cores
-        # (512 each); an operation is one add, multiply or divide.  (The kernel deals one
-        # component of a corner's rows to a lane and spends 32 stages of each kind.)
-        flops_unit = 13 * 26 + 31 * 36 + 30 * 2 + 2 + 2 * 512
+        # residual, and two rank-1 updates of the SYMMETRIC 16 x 16 Gram matrix (the upper
+        # triangle: 136 multiply-adds = 272 operations each; the matrix instruction computes
+        # all 256 entries, the other 120 are not counted); an operation is one add, multiply
+        # or divide.  (The kernel deals one component of a corner's rows to a lane and spends 32
+        # stages of each kind.)
+        flops_unit = 13 * 26 + 31 * 36 + 30 * 2 + 2 + 2 * 272
         flops_eval = flops_unit * 2.0 * V * C
         tf = flops_eval / (eval_ms * 1e-3) / 1e12
         calibration = {
