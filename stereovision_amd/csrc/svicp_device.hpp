@@ -1606,7 +1606,7 @@ __device__ __forceinline__ bool tile_cannot_move(const float4 *rec, const double
 // Whatever the flags say, every tile is worked on exactly once: by the block it is dealt to if
 // its bit is set, by its fixed block if not (the row is not written during the launch).
 constexpr int kManyRounds = 32;
-constexpr int kManyFlagWords = 512;     // flag words kept in LDS: 32768 tiles (beyond: fixed shares only)
+constexpr int kManyFlagWords = 1024;    // flag words kept in LDS: 65536 tiles (beyond: fixed shares only)
 constexpr int kManyTurn = 173;
 __device__ __forceinline__ int many_tile(int first, int round, int blocks, int share)
 {

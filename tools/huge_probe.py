@@ -16,6 +16,7 @@ X, I = c.history()
 s = c.search_counts()
 print(f"30 iterations in {dt * 1e3:.1f} ms; inliers first/last {I[0, 0] / len(src):.3f} {I[-1, 0] / len(src):.3f}; "
       f"searched {s[:4].astype(np.int64)} .. {int(s[-1])}; |T P - I| {np.abs(T @ P - np.eye(4)).max():.2e}; status {info.status}", flush=True)
+print("tiles left unread in iterations 4, 10, 29:", c.tiles_left_unread()[[4, 10, 29]], "of", (len(src) + 1023) // 1024, flush=True)
 idx, d2 = c.correspondences()
 print("matched share", float((idx >= 0).mean()))
 t0 = time.perf_counter(); n2 = c.get_normals() if False else None
