@@ -448,37 +448,62 @@ int run_nn1_on(svicp_ctx *ctx, const float *x, const float *y, const float *z, c
                            (int *)nullptr, (int4 *)nullptr, (int *)nullptr);
         LAUNCHCHK("nn1_kernel");
     } else {
-        // counters: [0] queries left for the exhaustive pass, [1], [2] entries of the lists of parts
-        // of waves that nn1_far_kernel hands on (4 lanes, then single lanes)
-        HIPCHK(ctx->scr->n_unres.reserve(sizeof(int) * 4));
-        HIPCHK(hipMemsetAsync(ctx->scr->n_unres.p, 0, sizeof(int) * 4, ctx->stream));
+        // The levels of the shared-box pass: {lanes of a wave an entry stands for, largest box in
+        // blocks}.  Level 0 takes whole waves of the search kernel; a wave whose box gets too large
+        // hands its open lanes on to the next level in parts, down to single lanes (a box around
+        // one query always works; what even that leaves goes to the exhaustive pass).
+        struct FarLevel { int lanes, max_blocks; };
+        static const std::vector<FarLevel> levels = [] {
+            std::vector<FarLevel> v;
+            const char *e = getenv("SVICP_FAR_LEVELS");          // development: "64:128,4:128,1:128"
+            for (const char *p = e; p && *p;) {
+                FarLevel L = { atoi(p), 128 };
+                if (const char *c = strchr(p, ':')) L.max_blocks = atoi(c + 1);
+                v.push_back(L);
+                p = strchr(p, ',');
+                if (p) ++p;
+            }
+            if (v.empty() || v[0].lanes != 64) v = { { 64, 128 }, { 4, 128 }, { 1, 128 } };
+            return v;
+        }();
+        const int nlev = (int)levels.size();
+        // counters: [0] queries left for the exhaustive pass, [l] entries of level l's list
+        HIPCHK(ctx->scr->n_unres.reserve(sizeof(int) * 8));
+        HIPCHK(hipMemsetAsync(ctx->scr->n_unres.p, 0, sizeof(int) * 8, ctx->stream));
         const int waves = cdiv(n, 64);
-        const int cap = (waves + 15) & ~15;
-        HIPCHK(ctx->scr->far_list.reserve(sizeof(int4) * (size_t)cap * 3));
+        std::vector<size_t> cap(nlev), off(nlev);
+        size_t total = 0;
+        for (int l = 0; l < nlev; ++l) {
+            // (every open lane of a level can end up as an entry of the next: never more than that)
+            cap[l] = l == 0 ? (size_t)waves : std::min<size_t>((size_t)cdiv(n, (int64_t)levels[l].lanes) + 64, (size_t)1 << 22);
+            off[l] = total;
+            total += cap[l];
+        }
+        HIPCHK(ctx->scr->far_list.reserve(sizeof(int4) * total));
         int *const n_unres = ctx->scr->n_unres.as<int>();
-        int4 *const list0 = ctx->scr->far_list.as<int4>(), *const list1 = list0 + cap, *const list2 = list1 + cap;
+        int4 *const lists = ctx->scr->far_list.as<int4>();
         // one chunk of 256 queries per block: the far queries, which take long, come in
         // stretches, and the dispatcher spreads them best when the blocks are small
         const int grid_exact = (int)std::min<int64_t>(cdiv(n, kBlockThreads), 1 << 20);
         hipLaunchKernelGGL((nn1_kernel<true, 4>), dim3(grid_exact), dim3(kBlockThreads), 0, ctx->stream,
                            ctx->g, x, y, z, perm, (int)n, ctx->opt.dist_threshold, idx, d2,
-                           ctx->scr->unresolved.as<int>(), n_unres, list0, (int *)nullptr);
+                           ctx->scr->unresolved.as<int>(), n_unres, lists, (int *)nullptr);
         LAUNCHCHK("nn1_kernel(exact)");
-        // the waves with queries beyond the probe radius: one candidate box per wave, in LDS (a grid
-        // that fills the GPU; every wave takes listed waves in turn).  A wave whose queries lie
-        // too far apart for one box hands them on to the next launch in 16 parts of 4 lanes, and
-        // such a part as single lanes (a box around one query always works).
+        // one candidate box per wave, in LDS (a grid that fills the GPU; every wave takes listed
+        // entries in turn)
         const int grid_far = (int)std::min<int64_t>(cdiv(waves, kFarThreads / 64), (int64_t)ctx->num_cus * 32);
         const dim3 fb(kFarThreads);
         int *const unres = ctx->scr->unresolved.as<int>();
-        hipLaunchKernelGGL(nn1_far_kernel, dim3(grid_far), fb, 0, ctx->stream, ctx->g, x, y, z, perm, (int)n, list0,
-                           (const int *)nullptr, waves, list1, n_unres + 1, cap, 16, 4, idx, d2, unres, n_unres);
-        hipLaunchKernelGGL(nn1_far_kernel, dim3(std::min(grid_far, 2048)), fb, 0, ctx->stream, ctx->g, x, y, z, perm,
-                           (int)n, list1, n_unres + 1, cap, list2, n_unres + 2, cap, 4, 1, idx, d2, unres, n_unres);
-        hipLaunchKernelGGL(nn1_far_kernel, dim3(std::min(grid_far, 2048)), fb, 0, ctx->stream, ctx->g, x, y, z, perm,
-                           (int)n, list2, n_unres + 2, cap, (int4 *)nullptr, (int *)nullptr, 0, 1, 1, idx, d2, unres,
-                           n_unres);
-        LAUNCHCHK("nn1_far_kernel");
+        for (int l = 0; l < nlev; ++l) {
+            const bool last = l + 1 == nlev;
+            const int next_lanes = last ? 1 : levels[l + 1].lanes;
+            hipLaunchKernelGGL(nn1_far_kernel, dim3(l == 0 ? grid_far : std::min(grid_far, 2048)), fb, 0, ctx->stream,
+                               ctx->g, x, y, z, perm, (int)n, lists + off[l], l == 0 ? (const int *)nullptr : n_unres + l,
+                               (int)cap[l], last ? (int4 *)nullptr : lists + off[l + 1], last ? (int *)nullptr : n_unres + l + 1,
+                               last ? 0 : (int)cap[l + 1], last ? 1 : levels[l].lanes / next_lanes, next_lanes,
+                               levels[l].max_blocks, idx, d2, unres, n_unres);
+            LAUNCHCHK("nn1_far_kernel");
+        }
         hipLaunchKernelGGL(nn1_brute_kernel, dim3(std::min<int64_t>(n, 2048)), dim3(kBlockThreads),
                            0, ctx->stream, ctx->g, x, y, z, perm, ctx->scr->unresolved.as<int>(),
                            n_unres, idx, d2);

@@ -1959,7 +1959,8 @@ struct FarStage {
 // Returns false when a box got too large (the open queries lie far apart: a wave that straddles
 // a jump of the Morton order); the caller then offers the lanes still open part by part.
 __device__ __forceinline__ bool far_search_wave(const GridDesc &g, float qx, float qy, float qz, bool open,
-                                                float &best, int &bidx, bool &done, FarStage &st, FarCounters &fc)
+                                                float &best, int &bidx, bool &done, FarStage &st, FarCounters &fc,
+                                                const int max_blocks = kFarMaxBlocks)
 {
     const int lane = threadIdx.x & 63;
     constexpr unsigned long long kNoKey = ((unsigned long long)0x7f800000u << 32) | 0xffffffffu;
@@ -1997,7 +1998,7 @@ __device__ __forceinline__ bool far_search_wave(const GridDesc &g, float qx, flo
         const int bx0 = x0 >> 2, by0 = y0 >> 2, bz0 = z0 >> 2;
         const int nbxs = (x1 >> 2) - bx0 + 1, nbys = (y1 >> 2) - by0 + 1, nbzs = (z1 >> 2) - bz0 + 1;
         const int nblk = nbxs * nbys * nbzs;
-        if (nblk > kFarMaxBlocks) { SVICP_FAR_COUNT(6, 1); return false; }
+        if (nblk > max_blocks) { SVICP_FAR_COUNT(6, 1); return false; }
         SVICP_FAR_COUNT(2, nblk);
         // the radius around this lane's query the box is certain to cover (as ring_box)
         float rho = INFINITY;
@@ -2315,7 +2316,7 @@ __global__ __launch_bounds__(kFarThreads, 4) void nn1_far_kernel(
     GridDesc g, const float *__restrict__ qx_, const float *__restrict__ qy_,
     const float *__restrict__ qz_, const int *__restrict__ perm, int n, const int4 *__restrict__ far_list,
     const int *__restrict__ n_far, int far_capacity, int4 *__restrict__ next_list, int *__restrict__ n_next, int next_capacity,
-    int parts, int part_lanes, int *__restrict__ idx_out, float *__restrict__ d2_out,
+    int parts, int part_lanes, int max_blocks, int *__restrict__ idx_out, float *__restrict__ d2_out,
     int *__restrict__ unresolved, int *__restrict__ n_unresolved)
 {
     constexpr int W = kFarThreads / 64;
@@ -2335,7 +2336,7 @@ __global__ __launch_bounds__(kFarThreads, 4) void nn1_far_kernel(
         float best = INFINITY;
         int bidx = -1;
         bool done = false;
-        const bool ok = far_search_wave(g, qx, qy, qz, open, best, bidx, done, stage[wv], fc);
+        const bool ok = far_search_wave(g, qx, qy, qz, open, best, bidx, done, stage[wv], fc, max_blocks);
         bool passed_on = false;
         if (!ok && next_list) {
             // the lanes still open, in four parts, to the next launch
@@ -2348,7 +2349,7 @@ __global__ __launch_bounds__(kFarThreads, 4) void nn1_far_kernel(
                 passed_on = true;
                 if (lane < parts) {
                     const int low = (int)(__ffsll((long long)mask) - 1) & ~(parts * part_lanes - 1);
-                    const unsigned long long span = (1ull << part_lanes) - 1ull;
+                    const unsigned long long span = part_lanes >= 64 ? ~0ull : (1ull << part_lanes) - 1ull;
                     const unsigned long long m = left & (span << (low + lane * part_lanes));
                     next_list[slot + lane] = make_int4(entry.x, (int)(unsigned)m, (int)(unsigned)(m >> 32), 0);
                 }
