@@ -1599,18 +1599,17 @@ __device__ __forceinline__ bool tile_cannot_move(const float4 *rec, const double
 //    dealt out in turn -- the j-th of them to block j mod blocks -- because the work that is left
 //    late in a registration sits in runs and at power-of-two strides of the sorted source, and
 //    a block with several such tiles does them one after the other (8 to 10 us each);
-//  * every other tile belongs to a fixed block (tile r * blocks + b, turned by an odd number per
-//    round), which as a rule proves from the tile's box record that it cannot have moved.  While
-//    the first wave solves, the second reads the flags and the others fetch the box records of
-//    the block's fixed share, so that none of this costs a trip to memory per tile.
+//  * every other tile belongs to a fixed block (block b, in the order that keeps neighbours on one
+//    XCD, has the `share` consecutive tiles from b * share on), which as a rule proves from the
+//    tile's box record that it cannot have moved.  While the first wave solves, the second reads
+//    the flags and the others fetch the box records of the block's fixed share, so that none of
+//    this costs a trip to memory per tile.
 // Whatever the flags say, every tile is worked on exactly once: by the block it is dealt to if
 // its bit is set, by its fixed block if not (the row is not written during the launch).
 constexpr int kManyRounds = 32;
 constexpr int kManyFlagWords = 1024;    // flag words kept in LDS: 65536 tiles (beyond: fixed shares only)
-constexpr int kManyTurn = 173;
-__device__ __forceinline__ int many_tile(int first, int round, int blocks, int share)
+__device__ __forceinline__ int many_tile(int first, int round, int share)
 {
-    (void)blocks;
     return first * share + round;
 }
 
@@ -1631,7 +1630,7 @@ __global__ __launch_bounds__(kItThreads, SVICP_MANY_OCC) void icp_iterate_many_k
     const int words = (nb + 63) >> 6;
     const int blocks = (int)gridDim.x;
     const int first = xcd_contiguous((int)blockIdx.x, blocks);
-    const int share = (nb + blocks - 1) / blocks;
+    const int share = (nb + blocks - 1) / blocks;      // (at most kManyRounds: the launch sees to that)
     const int rounds = max(0, min(min(share, nb - first * share), kManyRounds));
     const bool provable = APPLY && CERTIFY && INPLACE && ps_box != nullptr;
     const bool dealing = APPLY && ps_active != nullptr && words <= kManyFlagWords;
@@ -1678,7 +1677,7 @@ __global__ __launch_bounds__(kItThreads, SVICP_MANY_OCC) void icp_iterate_many_k
         } else if (provable) {
             for (int w = (int)threadIdx.x - 128; w < rounds * kBoxRecord; w += kItThreads - 128) {
                 const int r = w / kBoxRecord;
-                records[r][w % kBoxRecord] = ps_box[(size_t)many_tile(first, r, blocks, share) * kBoxRecord + w % kBoxRecord];
+                records[r][w % kBoxRecord] = ps_box[(size_t)many_tile(first, r, share) * kBoxRecord + w % kBoxRecord];
             }
         }
     }
@@ -1690,7 +1689,7 @@ __global__ __launch_bounds__(kItThreads, SVICP_MANY_OCC) void icp_iterate_many_k
     // cloud has stopped moving, reading coordinates is all such a launch would still do. ----
     bool mine_to_do = false, proven = false;
     if (lane < rounds) {
-        const int t = many_tile(first, lane, blocks, share);
+        const int t = many_tile(first, lane, share);
         const bool is_dealt = dealing && ((flags[t >> 6] >> (t & 63)) & 1ull);
         proven = !is_dealt && provable && tile_cannot_move(records[lane], rt);
         mine_to_do = !is_dealt && !proven;
@@ -1713,7 +1712,7 @@ __global__ __launch_bounds__(kItThreads, SVICP_MANY_OCC) void icp_iterate_many_k
             // the (i - n_dealt)-th set bit of todo
             unsigned m = todo;
             for (int k = n_dealt; k < i; ++k) m &= m - 1u;
-            tile = many_tile(first, __ffs(m) - 1, blocks, share);
+            tile = many_tile(first, __ffs(m) - 1, share);
         }
         iterate_tile<APPLY, CERTIFY, CH, INPLACE, true>(*grid, sx_in, sy_in, sz_in, sx_out, sy_out, sz_out, n,
                                                         totals, deltas, fx, st, X_hist, info_hist, iter, cp, ps,
