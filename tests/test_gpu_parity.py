@@ -266,14 +266,16 @@ def test_coherent_search_matches_full_search(ctx, pair):
     ctx.set_options(coherent=1)
 
 
-def test_large_source_leaves_settled_tiles_unread(ctx):
-    """4096 tiles (the smallest source that counts as large): the launches from the fifth on run
+@pytest.mark.parametrize("side", [2048, 2100])
+def test_large_source_leaves_settled_tiles_unread(ctx, side):
+    """4096 tiles (the smallest source that counts as large) and 4307 (the last tile partly filled,
+    the tiles not a multiple of the blocks): the launches from the fifth on run
     one round of blocks that work through several tiles each, deal out the tiles that had work in
     the launch before and leave unread those whose box records prove that no point of them can
     change.  With the proofs switched off every tile is read; the results must be the same
     bits, and agree with a run that searches every point in every iteration."""
     from stereovision_amd import synth
-    tgt, nrm, src, P = synth.make_pair(2048, inlier_frac=0.7)
+    tgt, nrm, src, P = synth.make_pair(side, inlier_frac=0.7)
     assert (len(src) + 1023) // 1024 >= 4096
     ctx.set_target(tgt, nrm)
     res = []
